@@ -1,0 +1,95 @@
+// Internal declarations shared by the HIP translation units of libtadmm_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave = 64 lanes, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/tadmm.h"
+
+namespace tadmm {
+
+constexpr int kWave = 64;
+
+// block -> (problem, local block) map used by every grouped launch
+struct BlockRef { int32_t prob; int32_t local; };
+
+// ---------------------------------------------------------------- sweep kernels
+// One compressed parameter as seen by the unfold / fold+update sweeps.
+//   conv (K2>1): W is (O, I, K2) row-major, the unfolded tensor T is (O, K2, I)
+//   K2==1      : no permutation, flat copy
+struct SweepDesc {
+  const float* W; float* U; float* Z;
+  float* T0;          // unfolded W+U (input of TT step 0)
+  const float* Zmat;  // reconstructed Z in unfolded layout
+  int32_t O, I, K2;
+  int32_t ichunk;     // input channels per block (conv) or elements per block (flat)
+  int32_t nchunk;     // chunks per o-slab (conv) ; total chunks (flat)
+  int64_t numel;
+  int32_t blk_begin;  // first global block of this layer (for the residual partials)
+  int32_t nblk;
+};
+
+void launch_unfold(const SweepDesc* descs_dev, const BlockRef* map_dev, int nblocks, int use_u, hipStream_t s);
+void launch_fold_update(const SweepDesc* descs_dev, const BlockRef* map_dev, int nblocks, int update_u,
+                        double* resid_partial_dev, hipStream_t s);
+void launch_resid_reduce(const SweepDesc* descs_dev, int nlayers, const double* resid_partial_dev,
+                         double* resid_sq_dev, hipStream_t s);
+
+// ---------------------------------------------------------------- Gram (fp64 MFMA)
+struct GramDesc {
+  const float* A;     // row-major m x n
+  int32_t m, n;
+  int32_t trans;      // 0: G = A A^T (N=m, reduce over n) ; 1: G = A^T A (N=n, reduce over m)
+  int32_t N, K;
+  int32_t nt;         // number of 32-wide tiles along N
+  int32_t ksplit, kchunk;
+  double* partial;    // [ksplit][ntp][32*32]
+  double* G;          // [Npad][ld]  (row j = column j of the symmetric matrix), zero padded
+  int32_t Npad, ld;
+};
+void launch_gram_partial(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+void launch_gram_reduce(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+
+// ---------------------------------------------------------------- Jacobi eigen-solver
+constexpr int kJB = 8;          // columns per block; a pair is 2*kJB = 16 columns = one MFMA tile
+struct EigDesc {
+  double* XT;         // [Npad][ld]: row j holds column j of X (starts as G, converges to G*V)
+  int32_t N, Npad, ld, nb;       // nb = Npad / kJB (even)
+  double* off;        // [3]: [0],[1] max relative off-diagonal per sweep parity; [2] max squared column norm
+  int32_t* done;      // [1] sticky convergence flag
+  // finalize outputs
+  double* lam;        // [Npad] eigenvalues (column norms), unsorted
+  int32_t* order;     // [Npad] order[c] = column index of c-th largest
+  double* sigma;      // [r] sqrt(lam) of kept columns, descending
+  int32_t r;          // kept rank
+  int32_t mode;       // 0: left vectors  (m<=n): Uf[m][r] = V           (core), needs project GEMM
+                      // 1: right vectors (m>n) : Vs[n][r] = V/sigma, Tn[r][n] = sigma*V^T ; 2: evec_out only
+  float* out_a;       // mode0: Uf (N x r) ; mode1: Vs (N x r)
+  float* out_b;       // mode1: Tnext (r x N) ; mode0: unused
+  double* evec_out;   // optional: [r][N] eigenvectors as rows in fp64 (tadmm_eigh_f64), nullable
+};
+void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s);
+void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
+                        int inner_sweeps, hipStream_t s);
+void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s);
+void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+
+// ---------------------------------------------------------------- grouped GEMM (fp32 MFMA)
+struct GemmDesc {
+  const float* A; const float* B; float* C;
+  int32_t M, N, K;
+  int64_t a_rs, a_cs, b_rs, b_cs, c_rs, c_cs;
+  float alpha, beta;
+  const float* bias_n; const float* bias_m;
+  int32_t tiles_m, tiles_n;
+};
+constexpr int kGemmBM = 64, kGemmBN = 64;
+void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+
+// ---------------------------------------------------------------- penalty
+constexpr int kPenaltyBlocks = 1024;
+void launch_penalty(int n, const void* const* ptrs_dev, const int64_t* numel_dev, int64_t total, float rho,
+                    float gscale, double* loss_dev, double* partial_dev, hipStream_t s);
+
+}  // namespace tadmm

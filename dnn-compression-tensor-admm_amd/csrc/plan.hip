@@ -1,0 +1,906 @@
+// Host side of libtadmm_hip.so: the C ABI of include/tadmm.h and the phase scheduler that turns a set
+// of layers into grouped launches.
+//
+// One ADMM projection (reference ADMM.update, admm.py:42-78) over L layers runs as
+//     unfold (1 launch)                                   T0 = unfold(W+U)
+//     for TT step s = 0 .. max(d)-2, over every layer that has that step:
+//         gram_partial, gram_reduce                       G = A A^T | A^T A              (fp64 MFMA)
+//         jacobi_init, jacobi_tick x (sweeps*(nb-1))      eigen-decomposition of G       (fp64 MFMA)
+//         eig_norms, eig_sort, eig_extract                top-r vectors, sigma
+//         gemm                                            T_{s+1} = U_r^T A | core = A V S^-1 (fp32 MFMA)
+//     gemm x (chain depth)                                Zmat = core_0 (core_1 (... T_{d-1}))
+//     fold_update, resid_reduce                           Z, U += W-Z, ||W-Z||^2
+// Layers are independent, so every launch is *grouped*: its blocks are mapped to
+// (layer, local block) through a BlockRef table built once at plan creation.  All descriptors live in
+// the caller-provided workspace; tadmm_plan_run allocates nothing.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tadmm;
+
+struct tadmm_ctx_s {
+  int device = 0;
+  std::string err;
+};
+
+#define CTX_FAIL(h, code, ...)                                   \
+  do {                                                           \
+    char _b[512];                                                \
+    snprintf(_b, sizeof _b, __VA_ARGS__);                        \
+    if (h) (h)->err = _b;                                        \
+    return (code);                                               \
+  } while (0)
+
+#define HIP_OK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (call);                                                                          \
+    if (_e != hipSuccess) CTX_FAIL(h, TADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+// layer geometry
+// ------------------------------------------------------------------------------------------------
+struct StepGeom {
+  int m = 0;            // rows of the unfolding  r_s * n_s
+  int64_t cols = 0;     // columns of the unfolding
+  int r = 0;            // kept rank r_{s+1}
+  bool skip = false;    // identity step (Z-only mode)
+  bool trans = false;   // m > cols : eigen-solve on A^T A
+  int N = 0, Npad = 0, ld = 0, nb = 0;
+  int nt = 0, ksplit = 0, kchunk = 0;
+};
+
+struct LayerGeom {
+  tadmm_layer_desc desc;
+  int64_t numel = 0;
+  int O = 0, I = 0, K2 = 1;   // K2 > 1 -> conv permutation
+  int d = 0;
+  std::vector<StepGeom> steps;  // d-1 entries
+};
+
+static int clamp_ranks(tadmm_layer_desc* d) {
+  int changed = 0;
+  int64_t tail = 1;
+  for (int i = 0; i < d->d; ++i) tail *= d->tt_shapes[i];
+  // reference ttd.py:15-19: unfolding i is (r_i*n_i) x (tail / n_i ...) with the *already clamped* r_i
+  int64_t rest = tail;
+  for (int i = 0; i + 1 < d->d; ++i) {
+    rest /= d->tt_shapes[i];
+    const int64_t m = (int64_t)d->ranks[i] * d->tt_shapes[i];
+    const int64_t ns = std::min<int64_t>(m, rest);
+    if (ns < d->ranks[i + 1]) { d->ranks[i + 1] = (int32_t)ns; ++changed; }
+  }
+  return changed;
+}
+
+static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g) {
+  g.desc = din;
+  tadmm_layer_desc& d = g.desc;
+  if (d.ndim != 2 && d.ndim != 4) CTX_FAIL(h, TADMM_ERR_INVALID, "ndim must be 2 or 4 (got %d)", d.ndim);
+  g.numel = 1;
+  for (int i = 0; i < d.ndim; ++i) {
+    if (d.dims[i] <= 0) CTX_FAIL(h, TADMM_ERR_INVALID, "non-positive dim");
+    g.numel *= d.dims[i];
+  }
+  if (d.kind == TADMM_KIND_TUCKER2) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "Tucker layers use tadmm_tucker_* (not in a TT plan)");
+  g.O = (int)d.dims[0];
+  g.I = (int)d.dims[1];
+  g.K2 = 1;
+  if (d.kind == TADMM_KIND_TT_CONV) {
+    if (d.ndim != 4) CTX_FAIL(h, TADMM_ERR_INVALID, "TT_CONV needs a 4-D weight");
+    g.K2 = (int)(d.dims[2] * d.dims[3]);
+  } else if (d.kind == TADMM_KIND_SVD) {
+    // admm.py:129-149: squeeze to (O,I); a 4-D weight must be 1x1
+    if (d.ndim == 4 && d.dims[2] * d.dims[3] != 1) CTX_FAIL(h, TADMM_ERR_INVALID, "SVD format needs a 1x1 kernel");
+    d.d = 2;
+    d.tt_shapes[0] = g.O; d.tt_shapes[1] = g.I;
+    const int r = d.ranks[0];
+    d.ranks[0] = 1; d.ranks[1] = r; d.ranks[2] = 1;
+  }
+  if (d.d < 2 || d.d > TADMM_MAX_MODES) CTX_FAIL(h, TADMM_ERR_INVALID, "number of TT modes must be in [2,%d]", TADMM_MAX_MODES);
+  int64_t prod = 1;
+  for (int i = 0; i < d.d; ++i) {
+    if (d.tt_shapes[i] <= 0) CTX_FAIL(h, TADMM_ERR_INVALID, "non-positive tt_shape");
+    prod *= d.tt_shapes[i];
+  }
+  if (prod != g.numel) CTX_FAIL(h, TADMM_ERR_INVALID, "prod(tt_shapes)=%lld != numel=%lld", (long long)prod, (long long)g.numel);
+  if (d.ranks[0] != 1 || d.ranks[d.d] != 1) CTX_FAIL(h, TADMM_ERR_INVALID, "boundary TT ranks must be 1");
+  for (int i = 0; i <= d.d; ++i) if (d.ranks[i] <= 0) CTX_FAIL(h, TADMM_ERR_INVALID, "non-positive rank");
+  clamp_ranks(&d);
+  g.d = d.d;
+  g.steps.resize(d.d - 1);
+  int64_t rest = g.numel;
+  for (int s = 0; s + 1 < d.d; ++s) {
+    StepGeom& st = g.steps[s];
+    rest /= d.tt_shapes[s];
+    st.m = d.ranks[s] * d.tt_shapes[s];
+    st.cols = rest;
+    st.r = d.ranks[s + 1];
+    st.trans = (int64_t)st.m > st.cols;
+    st.N = (int)std::min<int64_t>(st.m, st.cols);
+    st.skip = (d.flags & TADMM_FLAG_SKIP_ROTATIONS) && !st.trans && st.r == st.m;
+    const int blk2 = 2 * kJB;
+    st.Npad = (int)align_up(st.N, blk2);
+    st.nb = st.Npad / kJB;
+    st.ld = (int)align_up(st.N, 32);
+    st.nt = (st.N + 31) / 32;
+    const int64_t K = st.trans ? st.m : st.cols;
+    const int ntp = st.nt * (st.nt + 1) / 2;
+    int ks = (1024 + ntp - 1) / ntp;
+    const int maxks = (int)std::max<int64_t>(1, (K + 255) / 256);
+    ks = std::max(1, std::min(ks, maxks));
+    st.kchunk = (int)align_up((K + ks - 1) / ks, 64);
+    st.ksplit = (int)((K + st.kchunk - 1) / st.kchunk);
+  }
+  return TADMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+struct Phase {  // one grouped launch: descriptor array + block map inside the device arena
+  size_t desc_off = 0, map_off = 0;
+  int nprob = 0, nblocks = 0;
+};
+
+struct StepPlan {
+  Phase gram_p, gram_r, eig_tick, eig_norm, eig_ext, proj;
+  size_t eig_desc_off = 0;
+  int neig = 0;
+  int gsteps = 0;                 // ticks per global sweep = max(nb-1)
+  size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
+  std::vector<int> nb;            // per problem
+  std::vector<int> layer_of;      // problem -> layer
+};
+
+struct tadmm_plan_s {
+  tadmm_handle h = nullptr;
+  int n = 0;
+  std::vector<LayerGeom> layers;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  Phase unfold, fold;
+  size_t sweep_desc_off = 0;
+  size_t resid_partial_off = 0;
+  int total_sweep_blocks = 0;
+  std::vector<StepPlan> steps;
+  std::vector<Phase> recon;       // chain levels
+  // per layer / step bookkeeping for queries
+  std::vector<std::vector<size_t>> sigma_off;   // [layer][step] -> offset of sigma doubles (or SIZE_MAX)
+  // timing
+  bool timing = false;
+  hipEvent_t ev[16];
+  bool ev_made = false;
+  double last_ms[8] = {0};
+  int last_sweeps = 0;
+  // host staging for the poll
+  std::vector<double> h_off;
+  std::vector<int> h_done;
+  double tol = 1e-9;
+  int inner_sweeps = 3;
+  int max_global_sweeps = 40;
+};
+
+namespace {
+
+// A simple bump allocator that is run twice: once with base==nullptr to size the workspace, once for real.
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(char* b) : base(b) {}
+  size_t take(size_t bytes, size_t align = 256) {
+    off = align_up(off, align);
+    const size_t o = off;
+    off += bytes;
+    return o;
+  }
+};
+
+struct HostImage {   // host copy of the descriptor part of the arena
+  std::vector<char> bytes;
+  void put(size_t off, const void* src, size_t n) {
+    if (bytes.size() < off + n) bytes.resize(off + n);
+    memcpy(bytes.data() + off, src, n);
+  }
+};
+
+struct Built {
+  // per layer buffers (offsets in the arena)
+  std::vector<size_t> tbuf0, tbuf1, xt, gpart, vs, cores_ws;
+};
+
+}  // namespace
+
+// Lays out the whole plan.  If `img` is null only sizes are computed.
+static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, float* const* Z, float* const* cores,
+                       HostImage* img, size_t desc_region, size_t* desc_bytes, size_t* total_bytes) {
+  tadmm_handle h = P->h;
+  const int n = P->n;
+  Arena da(P->ws);             // descriptors + block maps: [0, desc_region)
+  Arena ar(P->ws);             // data buffers: [desc_region, ...)
+  ar.off = desc_region;
+  auto dev = [&](size_t off) -> char* { return P->ws ? P->ws + off : nullptr; };
+
+  // ---- data buffers per layer ----
+  std::vector<size_t> tb0(n), tb1(n), xt(n), gp(n), vs(n), cw(n);
+  std::vector<std::vector<size_t>> core_off(n);     // float offsets (bytes) of core_s inside arena or user buf
+  std::vector<std::vector<float*>> core_ptr(n);     // device pointers of cores (incl. last = T_{d-1} when user buf)
+  P->sigma_off.assign(n, {});
+  for (int l = 0; l < n; ++l) {
+    const LayerGeom& g = P->layers[l];
+    tb0[l] = ar.take((size_t)g.numel * 4);
+    tb1[l] = ar.take((size_t)g.numel * 4);
+    size_t xtb = 0, gpb = 0, vsb = 0, cb = 0;
+    for (const StepGeom& st : g.steps) {
+      if (st.skip) continue;
+      xtb = std::max(xtb, (size_t)st.Npad * st.ld * 8);
+      gpb = std::max(gpb, (size_t)st.ksplit * (st.nt * (st.nt + 1) / 2) * 1024 * 8);
+      if (st.trans) vsb = std::max(vsb, (size_t)st.N * st.r * 4);
+      cb += align_up((size_t)st.m * st.r * 4, 256);
+    }
+    xt[l] = ar.take(xtb ? xtb : 256);
+    gp[l] = ar.take(gpb ? gpb : 256);
+    vs[l] = ar.take(vsb ? vsb : 256);
+    cw[l] = ar.take(cb ? cb : 256);
+    P->sigma_off[l].assign(g.steps.size(), (size_t)-1);
+  }
+
+  // ---- sweep descriptors (unfold / fold_update) ----
+  std::vector<SweepDesc> sd(n);
+  std::vector<BlockRef> smap;
+  // T pointer tracking: cur[l] = buffer holding T_s
+  std::vector<float*> cur(n), other(n);
+  for (int l = 0; l < n; ++l) {
+    const LayerGeom& g = P->layers[l];
+    SweepDesc& s = sd[l];
+    memset(&s, 0, sizeof s);
+    s.W = W ? W[l] : nullptr; s.U = U ? U[l] : nullptr; s.Z = Z ? Z[l] : nullptr;
+    s.T0 = (float*)dev(tb0[l]);
+    s.O = g.O; s.I = g.I; s.K2 = g.K2;
+    s.numel = g.numel;
+    if (g.K2 > 1) {
+      int ich = std::min(g.I, 256);
+      while ((int64_t)g.K2 * (ich + 1) > 12288 && ich > 1) ich /= 2;
+      s.ichunk = ich;
+      s.nchunk = (g.I + ich - 1) / ich;
+      s.nblk = g.O * s.nchunk;
+    } else {
+      s.ichunk = 8192;
+      s.nchunk = (int)((g.numel + s.ichunk - 1) / s.ichunk);
+      s.nblk = s.nchunk;
+    }
+    s.blk_begin = (int)smap.size();
+    for (int b = 0; b < s.nblk; ++b) smap.push_back(BlockRef{l, b});
+    cur[l] = (float*)dev(tb0[l]);
+    other[l] = (float*)dev(tb1[l]);
+  }
+  P->total_sweep_blocks = (int)smap.size();
+  P->resid_partial_off = ar.take((size_t)smap.size() * 8);
+
+  // ---- TT steps ----
+  int maxsteps = 0;
+  for (const LayerGeom& g : P->layers) maxsteps = std::max(maxsteps, (int)g.steps.size());
+  P->steps.assign(maxsteps, StepPlan());
+  // recon chain bookkeeping: for each layer the list of (core ptr, m, r, cols) of non-skipped steps
+  struct RecOp { const float* core; int m, r; int64_t cols; };
+  std::vector<std::vector<RecOp>> recops(n);
+  std::vector<const float*> lastT(n, nullptr);
+
+  for (int s = 0; s < maxsteps; ++s) {
+    StepPlan& sp = P->steps[s];
+    std::vector<GramDesc> gd;
+    std::vector<EigDesc> ed;
+    std::vector<GemmDesc> pd;
+    std::vector<BlockRef> m_gp, m_gr, m_tick, m_norm, m_ext, m_proj;
+    std::vector<int> layer_of;
+    for (int l = 0; l < n; ++l) {
+      const LayerGeom& g = P->layers[l];
+      if (s >= (int)g.steps.size()) continue;
+      const StepGeom& st = g.steps[s];
+      if (st.skip) {   // identity: T_{s+1} aliases T_s, no core
+        if (cores && cores[l]) CTX_FAIL(h, TADMM_ERR_INVALID, "TADMM_FLAG_SKIP_ROTATIONS is incompatible with cores output");
+        continue;
+      }
+      layer_of.push_back(l);
+    }
+    sp.neig = (int)layer_of.size();
+    sp.layer_of = layer_of;
+    sp.off_off = ar.take((size_t)std::max(1, sp.neig) * 3 * 8);
+    sp.done_off = ar.take((size_t)std::max(1, sp.neig) * 4);
+    sp.gsteps = 0;
+    for (int p = 0; p < sp.neig; ++p) {
+      const int l = layer_of[p];
+      const LayerGeom& g = P->layers[l];
+      const StepGeom& st = g.steps[s];
+      const bool last_step = (s + 2 == g.d);
+      // core storage
+      float* core_dev;
+      float* tnext;
+      if (cores && cores[l]) {
+        size_t off = 0;
+        for (int j = 0; j < s; ++j) off += (size_t)g.steps[j].m * g.steps[j].r;
+        core_dev = cores[l] + off;
+        tnext = last_step ? (cores[l] + off + (size_t)st.m * st.r) : other[l];
+      } else {
+        size_t off = 0;
+        for (int j = 0; j < s; ++j) if (!g.steps[j].skip) off += align_up((size_t)g.steps[j].m * g.steps[j].r * 4, 256);
+        core_dev = (float*)dev(cw[l] + off);
+        tnext = other[l];
+      }
+      const float* Tin = cur[l];
+      // Gram
+      GramDesc gdsc;
+      memset(&gdsc, 0, sizeof gdsc);
+      gdsc.A = Tin; gdsc.m = st.m; gdsc.n = (int)st.cols; gdsc.trans = st.trans ? 1 : 0;
+      gdsc.N = st.N; gdsc.K = st.trans ? st.m : (int)st.cols;
+      gdsc.nt = st.nt; gdsc.ksplit = st.ksplit; gdsc.kchunk = st.kchunk;
+      gdsc.partial = (double*)dev(gp[l]);
+      gdsc.G = (double*)dev(xt[l]);
+      gdsc.Npad = st.Npad; gdsc.ld = st.ld;
+      const int ntp = st.nt * (st.nt + 1) / 2;
+      for (int b = 0; b < st.ksplit * ntp; ++b) m_gp.push_back(BlockRef{p, b});
+      const int64_t gtot = (int64_t)st.Npad * st.ld;
+      for (int b = 0; b < (int)((gtot + 1023) / 1024); ++b) m_gr.push_back(BlockRef{p, b});
+      gd.push_back(gdsc);
+      // eig
+      EigDesc e;
+      memset(&e, 0, sizeof e);
+      e.XT = (double*)dev(xt[l]);
+      e.N = st.N; e.Npad = st.Npad; e.ld = st.ld; e.nb = st.nb;
+      e.off = (double*)dev(sp.off_off) + 3 * p;
+      e.done = (int32_t*)dev(sp.done_off) + p;
+      const size_t lam_off = ar.take((size_t)st.Npad * 8);
+      const size_t ord_off = ar.take((size_t)st.Npad * 4);
+      const size_t sig_off = ar.take((size_t)st.r * 8);
+      P->sigma_off[l][s] = sig_off;
+      e.lam = (double*)dev(lam_off);
+      e.order = (int32_t*)dev(ord_off);
+      e.sigma = (double*)dev(sig_off);
+      e.r = st.r;
+      e.mode = st.trans ? 1 : 0;
+      e.out_a = st.trans ? (float*)dev(vs[l]) : core_dev;
+      e.out_b = st.trans ? tnext : nullptr;
+      e.evec_out = nullptr;
+      ed.push_back(e);
+      sp.nb.push_back(st.nb);
+      sp.gsteps = std::max(sp.gsteps, st.nb - 1);
+      for (int b = 0; b < st.nb / 2; ++b) m_tick.push_back(BlockRef{p, b});
+      for (int b = 0; b < (st.Npad + 3) / 4; ++b) m_norm.push_back(BlockRef{p, b});
+      for (int b = 0; b < (st.r + 3) / 4; ++b) m_ext.push_back(BlockRef{p, b});
+      // projection GEMM
+      GemmDesc pg;
+      memset(&pg, 0, sizeof pg);
+      pg.alpha = 1.f; pg.beta = 0.f;
+      if (!st.trans) {   // T_{s+1}[r x cols] = Uf^T[r x m] * A[m x cols]
+        pg.A = core_dev; pg.a_rs = 1; pg.a_cs = st.r;
+        pg.B = Tin; pg.b_rs = st.cols; pg.b_cs = 1;
+        pg.C = tnext; pg.c_rs = st.cols; pg.c_cs = 1;
+        pg.M = st.r; pg.N = (int)st.cols; pg.K = st.m;
+      } else {           // core[m x r] = A[m x n] * Vs[n x r]
+        pg.A = Tin; pg.a_rs = st.cols; pg.a_cs = 1;
+        pg.B = (const float*)dev(vs[l]); pg.b_rs = st.r; pg.b_cs = 1;
+        pg.C = core_dev; pg.c_rs = st.r; pg.c_cs = 1;
+        pg.M = st.m; pg.N = st.r; pg.K = (int)st.cols;
+      }
+      pg.tiles_m = (pg.M + kGemmBM - 1) / kGemmBM;
+      pg.tiles_n = (pg.N + kGemmBN - 1) / kGemmBN;
+      for (int b = 0; b < pg.tiles_m * pg.tiles_n; ++b) m_proj.push_back(BlockRef{p, b});
+      pd.push_back(pg);
+      recops[l].push_back(RecOp{core_dev, st.m, st.r, st.cols});
+      // advance the T chain
+      if (tnext == other[l]) std::swap(cur[l], other[l]);
+      else { cur[l] = tnext; }
+    }
+    auto place = [&](Phase& ph, const void* descs, size_t dbytes, int nprob, const std::vector<BlockRef>& map) {
+      ph.nprob = nprob;
+      ph.nblocks = (int)map.size();
+      ph.desc_off = da.take(std::max<size_t>(dbytes, 16));
+      ph.map_off = da.take(std::max<size_t>(map.size() * sizeof(BlockRef), 16));
+      if (img) {
+        if (dbytes) img->put(ph.desc_off, descs, dbytes);
+        if (!map.empty()) img->put(ph.map_off, map.data(), map.size() * sizeof(BlockRef));
+      }
+    };
+    place(sp.gram_p, gd.data(), gd.size() * sizeof(GramDesc), sp.neig, m_gp);
+    sp.gram_r = sp.gram_p;
+    sp.gram_r.map_off = da.take(std::max<size_t>(m_gr.size() * sizeof(BlockRef), 16));
+    sp.gram_r.nblocks = (int)m_gr.size();
+    if (img && !m_gr.empty()) img->put(sp.gram_r.map_off, m_gr.data(), m_gr.size() * sizeof(BlockRef));
+    place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m_tick);
+    sp.eig_desc_off = sp.eig_tick.desc_off;
+    sp.eig_norm = sp.eig_tick;
+    sp.eig_norm.map_off = da.take(std::max<size_t>(m_norm.size() * sizeof(BlockRef), 16));
+    sp.eig_norm.nblocks = (int)m_norm.size();
+    if (img && !m_norm.empty()) img->put(sp.eig_norm.map_off, m_norm.data(), m_norm.size() * sizeof(BlockRef));
+    sp.eig_ext = sp.eig_tick;
+    sp.eig_ext.map_off = da.take(std::max<size_t>(m_ext.size() * sizeof(BlockRef), 16));
+    sp.eig_ext.nblocks = (int)m_ext.size();
+    if (img && !m_ext.empty()) img->put(sp.eig_ext.map_off, m_ext.data(), m_ext.size() * sizeof(BlockRef));
+    place(sp.proj, pd.data(), pd.size() * sizeof(GemmDesc), sp.neig, m_proj);
+  }
+
+  // ---- reconstruction chain, right to left:  R = T_{d-1};  R <- core_s * R ----
+  for (int l = 0; l < n; ++l) lastT[l] = cur[l];
+  size_t maxchain = 0;
+  for (int l = 0; l < n; ++l) maxchain = std::max(maxchain, recops[l].size());
+  P->recon.assign(maxchain, Phase());
+  std::vector<const float*> rcur(n);
+  std::vector<float*> rfree(n);
+  for (int l = 0; l < n; ++l) {
+    rcur[l] = lastT[l];
+    // the "other" ping-pong buffer is free; if T_{d-1} lives in the user's cores buffer both are free
+    float* b0 = (float*)dev(tb0[l]);
+    float* b1 = (float*)dev(tb1[l]);
+    rfree[l] = (rcur[l] == b0) ? b1 : b0;
+  }
+  for (size_t lev = 0; lev < maxchain; ++lev) {
+    std::vector<GemmDesc> rd;
+    std::vector<BlockRef> rmap;
+    for (int l = 0; l < n; ++l) {
+      if (lev >= recops[l].size()) continue;
+      const RecOp& op = recops[l][recops[l].size() - 1 - lev];
+      GemmDesc g;
+      memset(&g, 0, sizeof g);
+      g.alpha = 1.f;
+      g.A = op.core; g.a_rs = op.r; g.a_cs = 1;
+      g.B = rcur[l]; g.b_rs = op.cols; g.b_cs = 1;
+      g.C = rfree[l]; g.c_rs = op.cols; g.c_cs = 1;
+      g.M = op.m; g.N = (int)op.cols; g.K = op.r;
+      g.tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
+      g.tiles_n = (g.N + kGemmBN - 1) / kGemmBN;
+      const int p = (int)rd.size();
+      for (int b = 0; b < g.tiles_m * g.tiles_n; ++b) rmap.push_back(BlockRef{p, b});
+      rd.push_back(g);
+      // ping-pong: the old input buffer becomes free unless it is a user buffer
+      float* b0 = (float*)dev(tb0[l]);
+      float* b1 = (float*)dev(tb1[l]);
+      const float* produced = rfree[l];
+      rfree[l] = (produced == b0) ? b1 : b0;
+      rcur[l] = produced;
+    }
+    Phase& ph = P->recon[lev];
+    ph.nprob = (int)rd.size();
+    ph.nblocks = (int)rmap.size();
+    ph.desc_off = da.take(std::max<size_t>(rd.size() * sizeof(GemmDesc), 16));
+    ph.map_off = da.take(std::max<size_t>(rmap.size() * sizeof(BlockRef), 16));
+    if (img) {
+      if (!rd.empty()) img->put(ph.desc_off, rd.data(), rd.size() * sizeof(GemmDesc));
+      if (!rmap.empty()) img->put(ph.map_off, rmap.data(), rmap.size() * sizeof(BlockRef));
+    }
+  }
+  for (int l = 0; l < n; ++l) sd[l].Zmat = rcur[l];
+
+  // ---- sweep phase descriptors ----
+  P->sweep_desc_off = da.take(sd.size() * sizeof(SweepDesc));
+  P->unfold.desc_off = P->sweep_desc_off;
+  P->unfold.nprob = n;
+  P->unfold.nblocks = (int)smap.size();
+  P->unfold.map_off = da.take(smap.size() * sizeof(BlockRef));
+  P->fold = P->unfold;
+  if (img) {
+    img->put(P->sweep_desc_off, sd.data(), sd.size() * sizeof(SweepDesc));
+    img->put(P->unfold.map_off, smap.data(), smap.size() * sizeof(BlockRef));
+  }
+  *desc_bytes = align_up(da.off, 4096);
+  *total_bytes = align_up(ar.off, 256);   // when desc_region == 0 this is the data size alone
+  return TADMM_OK;
+}
+
+__global__ void square_copy_kernel(const double* __restrict__ in, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * in[i];
+}
+static void tadmm_square_copy(const double* in, double* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(square_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int tadmm_version(void) { return 100; }
+
+int tadmm_create(int device, tadmm_handle* out) {
+  if (!out) return TADMM_ERR_INVALID;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  tadmm_handle h = new tadmm_ctx_s();
+  h->device = device;
+  *out = h;
+  if (e != hipSuccess || device < 0 || device >= count) {
+    h->err = std::string("no usable HIP device ") + std::to_string(device) + " (" + hipGetErrorString(e) + ")";
+    return TADMM_ERR_HIP;
+  }
+  return TADMM_OK;
+}
+
+int tadmm_destroy(tadmm_handle h) {
+  delete h;
+  return TADMM_OK;
+}
+
+const char* tadmm_last_error(tadmm_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int tadmm_tt_clamp_ranks(tadmm_layer_desc* desc) {
+  if (!desc || desc->d < 2 || desc->d > TADMM_MAX_MODES) return TADMM_ERR_INVALID;
+  return clamp_ranks(desc);
+}
+
+int tadmm_plan_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, size_t* bytes) {
+  if (!h || !descs || !bytes || n_layers <= 0) return TADMM_ERR_INVALID;
+  tadmm_plan_s P;
+  P.h = h;
+  P.n = n_layers;
+  P.layers.resize(n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    int rc = build_geom(h, descs[l], P.layers[l]);
+    if (rc) return rc;
+  }
+  P.ws = nullptr;
+  size_t db = 0, data = 0;
+  int rc = layout_plan(&P, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &db, &data);
+  if (rc) return rc;
+  *bytes = db + data + 4096;
+  return TADMM_OK;
+}
+
+int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
+                      float* const* U, float* const* Z, float* const* cores, void* workspace, size_t workspace_bytes,
+                      tadmm_plan* out) {
+  if (!h || !descs || !W || !U || !Z || !workspace || !out || n_layers <= 0) return TADMM_ERR_INVALID;
+  tadmm_plan_s* P = new tadmm_plan_s();
+  P->h = h;
+  P->n = n_layers;
+  P->layers.resize(n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    int rc = build_geom(h, descs[l], P->layers[l]);
+    if (rc) { delete P; return rc; }
+  }
+  P->ws = (char*)workspace;
+  P->ws_bytes = workspace_bytes;
+  HostImage img;
+  size_t need = 0, db = 0, data0 = 0;
+  int rc = layout_plan(P, W, U, Z, cores, nullptr, 0, &db, &data0);      // pass 1: size of the descriptor region
+  if (rc) { delete P; return rc; }
+  rc = layout_plan(P, W, U, Z, cores, &img, db, &db, &need);             // pass 2: real offsets
+  if (rc) { delete P; return rc; }
+  if (need > workspace_bytes) {
+    delete P;
+    CTX_FAIL(h, TADMM_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  }
+  // descriptors were written at their arena offsets in the host image; upload the covered range
+  if (!img.bytes.empty()) {
+    hipError_t e = hipMemcpy(P->ws, img.bytes.data(), img.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "descriptor upload failed: %s", hipGetErrorString(e)); }
+  }
+  size_t maxe = 1;
+  for (const StepPlan& sp : P->steps) maxe = std::max<size_t>(maxe, sp.neig);
+  P->h_off.resize(maxe * 3);
+  P->h_done.resize(maxe);
+  *out = P;
+  return TADMM_OK;
+}
+
+int tadmm_plan_enable_timing(tadmm_plan p, int on) {
+  if (!p) return TADMM_ERR_INVALID;
+  if (on && !p->ev_made) {
+    for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) return TADMM_ERR_HIP;
+    p->ev_made = true;
+  }
+  p->timing = on != 0;
+  return TADMM_OK;
+}
+
+int tadmm_plan_last_timing(tadmm_plan p, double out_ms[8]) {
+  if (!p || !out_ms) return TADMM_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) out_ms[i] = p->last_ms[i];
+  out_ms[6] = p->last_sweeps;
+  return TADMM_OK;
+}
+
+int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_) {
+  if (!p) return TADMM_ERR_INVALID;
+  tadmm_handle h = p->h;
+  hipStream_t s = (hipStream_t)stream_;
+  char* ws = p->ws;
+  auto D = [&](size_t off) { return ws + off; };
+  double acc_ms[8] = {0};
+  int total_sweeps = 0;
+  // timing helper: record a pair of events around a phase and accumulate after a sync
+  auto tic = [&](int i) { if (p->timing) hipEventRecord(p->ev[i], s); };
+  auto toc = [&](int i, int slot) {
+    if (!p->timing) return;
+    hipEventRecord(p->ev[i + 1], s);
+    hipEventSynchronize(p->ev[i + 1]);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+    acc_ms[slot] += ms;
+  };
+
+  tic(0);
+  launch_unfold((const SweepDesc*)D(p->sweep_desc_off), (const BlockRef*)D(p->unfold.map_off), p->unfold.nblocks,
+                use_u, s);
+  toc(0, 0);
+
+  for (StepPlan& sp : p->steps) {
+    if (sp.neig == 0) continue;
+    tic(0);
+    launch_gram_partial((const GramDesc*)D(sp.gram_p.desc_off), (const BlockRef*)D(sp.gram_p.map_off),
+                        sp.gram_p.nblocks, s);
+    launch_gram_reduce((const GramDesc*)D(sp.gram_r.desc_off), (const BlockRef*)D(sp.gram_r.map_off),
+                       sp.gram_r.nblocks, s);
+    toc(0, 1);
+    tic(0);
+    const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
+    launch_jacobi_init(ed, sp.neig, s);
+    bool all_done = false;
+    int tick = 0;
+    int gs = 0;
+    for (; gs < p->max_global_sweeps && !all_done; ++gs) {
+      for (int t = 0; t < sp.gsteps; ++t, ++tick)
+        launch_jacobi_tick(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
+                           p->inner_sweeps, s);
+      HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
+      HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(h, hipStreamSynchronize(s));
+      all_done = true;
+      for (int q = 0; q < sp.neig; ++q) {
+        if (p->h_done[q]) continue;
+        const int steps = sp.nb[q] - 1;
+        bool conv = false;
+        if (tick % steps == 0) {   // this problem just finished its own sweep number tick/steps - 1
+          const int swp = tick / steps - 1;
+          conv = p->h_off[3 * q + (swp & 1)] < p->tol;
+        }
+        if (!conv) { all_done = false; break; }
+      }
+    }
+    total_sweeps += gs;
+    if (!all_done) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in %d sweeps", p->max_global_sweeps);
+    launch_eig_norms(ed, (const BlockRef*)D(sp.eig_norm.map_off), sp.eig_norm.nblocks, s);
+    launch_eig_sort(ed, sp.neig, s);
+    launch_eig_extract(ed, (const BlockRef*)D(sp.eig_ext.map_off), sp.eig_ext.nblocks, s);
+    toc(0, 2);
+    tic(0);
+    launch_gemm((const GemmDesc*)D(sp.proj.desc_off), (const BlockRef*)D(sp.proj.map_off), sp.proj.nblocks, s);
+    toc(0, 3);
+  }
+  tic(0);
+  for (Phase& ph : p->recon)
+    launch_gemm((const GemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, s);
+  toc(0, 4);
+  tic(0);
+  double* partial = (double*)D(p->resid_partial_off);
+  launch_fold_update((const SweepDesc*)D(p->sweep_desc_off), (const BlockRef*)D(p->fold.map_off), p->fold.nblocks,
+                     update_u, partial, s);
+  if (resid_sq_dev) launch_resid_reduce((const SweepDesc*)D(p->sweep_desc_off), p->n, partial, resid_sq_dev, s);
+  toc(0, 5);
+  HIP_OK(h, hipGetLastError());
+  for (int i = 0; i < 8; ++i) p->last_ms[i] = acc_ms[i];
+  p->last_sweeps = total_sweeps;
+  return TADMM_OK;
+}
+
+int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_host, void* stream_) {
+  if (!p || !out_host || layer < 0 || layer >= p->n) return TADMM_ERR_INVALID;
+  const LayerGeom& g = p->layers[layer];
+  if (step < 0 || step >= (int)g.steps.size()) return TADMM_ERR_INVALID;
+  const size_t off = p->sigma_off[layer][step];
+  if (off == (size_t)-1) CTX_FAIL(p->h, TADMM_ERR_INVALID, "step %d of layer %d was skipped (identity)", step, layer);
+  hipStream_t s = (hipStream_t)stream_;
+  HIP_OK(p->h, hipMemcpyAsync(out_host, p->ws + off, (size_t)g.steps[step].r * 8, hipMemcpyDeviceToHost, s));
+  HIP_OK(p->h, hipStreamSynchronize(s));
+  return TADMM_OK;
+}
+
+int tadmm_plan_destroy(tadmm_plan p) {
+  if (!p) return TADMM_OK;
+  if (p->ev_made) for (auto& e : p->ev) hipEventDestroy(e);
+  delete p;
+  return TADMM_OK;
+}
+
+int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out) {
+  if (!p || !ranks_out || layer < 0 || layer >= p->n) return TADMM_ERR_INVALID;
+  const tadmm_layer_desc& d = p->layers[layer].desc;
+  for (int i = 0; i <= d.d; ++i) ranks_out[i] = d.ranks[i];
+  return d.d + 1;
+}
+
+// ---- penalty ----
+int tadmm_penalty_scratch_doubles(void) { return kPenaltyBlocks; }
+
+int tadmm_penalty(tadmm_handle h, int n, const void* const* ptrs_dev, const int64_t* numel_dev, int64_t total_numel,
+                  float rho, float grad_scale, double* loss_dev, double* partial_dev, void* stream_) {
+  if (!h || n <= 0 || !ptrs_dev || !numel_dev || !loss_dev || !partial_dev) return TADMM_ERR_INVALID;
+  launch_penalty(n, ptrs_dev, numel_dev, total_numel, rho, grad_scale, loss_dev, partial_dev, (hipStream_t)stream_);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+// ---- grouped GEMM ----
+size_t tadmm_gemm_pack_bytes(int n, const tadmm_gemm_desc* descs) {
+  if (n <= 0 || !descs) return 0;
+  size_t blocks = 0;
+  for (int i = 0; i < n; ++i)
+    blocks += (size_t)((descs[i].M + kGemmBM - 1) / kGemmBM) * ((descs[i].N + kGemmBN - 1) / kGemmBN);
+  return align_up((size_t)n * sizeof(GemmDesc), 256) + blocks * sizeof(BlockRef);
+}
+
+int tadmm_gemm_pack(int n, const tadmm_gemm_desc* descs, void* blob_host, size_t blob_bytes, int* nblocks_out) {
+  if (n <= 0 || !descs || !blob_host || !nblocks_out) return TADMM_ERR_INVALID;
+  if (blob_bytes < tadmm_gemm_pack_bytes(n, descs)) return TADMM_ERR_WORKSPACE;
+  GemmDesc* gd = (GemmDesc*)blob_host;
+  BlockRef* map = (BlockRef*)((char*)blob_host + align_up((size_t)n * sizeof(GemmDesc), 256));
+  int nb = 0;
+  for (int i = 0; i < n; ++i) {
+    const tadmm_gemm_desc& s = descs[i];
+    if (s.M <= 0 || s.N <= 0 || s.K <= 0) return TADMM_ERR_INVALID;
+    if (!((s.a_rs == 1) || (s.a_cs == 1)) || !((s.b_rs == 1) || (s.b_cs == 1))) return TADMM_ERR_INVALID;
+    GemmDesc& g = gd[i];
+    memset(&g, 0, sizeof g);
+    g.A = s.A; g.B = s.B; g.C = s.C; g.M = s.M; g.N = s.N; g.K = s.K;
+    g.a_rs = s.a_rs; g.a_cs = s.a_cs; g.b_rs = s.b_rs; g.b_cs = s.b_cs; g.c_rs = s.c_rs; g.c_cs = s.c_cs;
+    g.alpha = s.alpha; g.beta = s.beta; g.bias_n = s.bias_n; g.bias_m = s.bias_m;
+    g.tiles_m = (s.M + kGemmBM - 1) / kGemmBM;
+    g.tiles_n = (s.N + kGemmBN - 1) / kGemmBN;
+    for (int b = 0; b < g.tiles_m * g.tiles_n; ++b) map[nb++] = BlockRef{i, b};
+  }
+  *nblocks_out = nb;
+  return TADMM_OK;
+}
+
+int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, void* stream_) {
+  if (!h || !blob_dev || n <= 0 || nblocks <= 0) return TADMM_ERR_INVALID;
+  const GemmDesc* gd = (const GemmDesc*)blob_dev;
+  const BlockRef* map = (const BlockRef*)((const char*)blob_dev + align_up((size_t)n * sizeof(GemmDesc), 256));
+  launch_gemm(gd, map, nblocks, (hipStream_t)stream_);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+// ---- standalone Gram / eigh (tests, Tucker path) ----
+static void gram_geom(int m, int n, StepGeom& st) {
+  st.m = m; st.cols = n; st.trans = m > n;
+  st.N = std::min(m, n);
+  st.Npad = (int)align_up(st.N, 2 * kJB);
+  st.nb = st.Npad / kJB;
+  st.ld = (int)align_up(st.N, 32);
+  st.nt = (st.N + 31) / 32;
+  const int64_t K = st.trans ? m : n;
+  const int ntp = st.nt * (st.nt + 1) / 2;
+  int ks = (1024 + ntp - 1) / ntp;
+  const int maxks = (int)std::max<int64_t>(1, (K + 255) / 256);
+  ks = std::max(1, std::min(ks, maxks));
+  st.kchunk = (int)align_up((K + ks - 1) / ks, 64);
+  st.ksplit = (int)((K + st.kchunk - 1) / st.kchunk);
+}
+
+size_t tadmm_gram_scratch_bytes(int m, int n) {
+  StepGeom st;
+  gram_geom(m, n, st);
+  const size_t ntp = (size_t)st.nt * (st.nt + 1) / 2;
+  const size_t nblk_p = (size_t)st.ksplit * ntp;
+  const size_t nblk_r = ((size_t)st.Npad * st.ld + 1023) / 1024;
+  return align_up(st.ksplit * ntp * 1024 * 8, 256) + align_up(sizeof(GramDesc), 256) +
+         align_up(nblk_p * sizeof(BlockRef), 256) + align_up(nblk_r * sizeof(BlockRef), 256);
+}
+
+int tadmm_gram_ld(int m, int n, int* Npad, int* ld) {
+  StepGeom st;
+  gram_geom(m, n, st);
+  if (Npad) *Npad = st.Npad;
+  if (ld) *ld = st.ld;
+  return st.N;
+}
+
+int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int ldg, void* scratch, size_t scratch_bytes,
+                   void* stream_) {
+  if (!h || !A || !G || !scratch || m <= 0 || n <= 0) return TADMM_ERR_INVALID;
+  StepGeom st;
+  gram_geom(m, n, st);
+  if (ldg != st.ld) CTX_FAIL(h, TADMM_ERR_INVALID, "ldg must be %d (tadmm_gram_ld)", st.ld);
+  if (scratch_bytes < tadmm_gram_scratch_bytes(m, n)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "gram scratch too small");
+  hipStream_t s = (hipStream_t)stream_;
+  const size_t ntp = (size_t)st.nt * (st.nt + 1) / 2;
+  char* base = (char*)scratch;
+  size_t off = 0;
+  double* partial = (double*)(base + off); off += align_up(st.ksplit * ntp * 1024 * 8, 256);
+  GramDesc* gdev = (GramDesc*)(base + off); off += align_up(sizeof(GramDesc), 256);
+  std::vector<BlockRef> mp, mr;
+  for (int b = 0; b < (int)(st.ksplit * ntp); ++b) mp.push_back(BlockRef{0, b});
+  for (int b = 0; b < (int)(((size_t)st.Npad * st.ld + 1023) / 1024); ++b) mr.push_back(BlockRef{0, b});
+  BlockRef* mpd = (BlockRef*)(base + off); off += align_up(mp.size() * sizeof(BlockRef), 256);
+  BlockRef* mrd = (BlockRef*)(base + off);
+  GramDesc gd;
+  memset(&gd, 0, sizeof gd);
+  gd.A = A; gd.m = m; gd.n = n; gd.trans = st.trans; gd.N = st.N; gd.K = st.trans ? m : n; gd.nt = st.nt;
+  gd.ksplit = st.ksplit; gd.kchunk = st.kchunk; gd.partial = partial; gd.G = G; gd.Npad = st.Npad; gd.ld = st.ld;
+  HIP_OK(h, hipMemcpyAsync(gdev, &gd, sizeof gd, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(mpd, mp.data(), mp.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(mrd, mr.data(), mr.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipStreamSynchronize(s));   // host vectors die at return
+  launch_gram_partial(gdev, mpd, (int)mp.size(), s);
+  launch_gram_reduce(gdev, mrd, (int)mr.size(), s);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+size_t tadmm_eigh_scratch_bytes(int N) {
+  const size_t Npad = align_up(N, 2 * kJB), ld = align_up(N, 32);
+  return align_up(Npad * ld * 8, 256) + align_up(sizeof(EigDesc), 256) + 4 * align_up(Npad * sizeof(BlockRef), 256) +
+         align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024;
+}
+
+int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, double* evecs_out, void* scratch,
+                   size_t scratch_bytes, int* sweeps_out, void* stream_) {
+  if (!h || !G || !evals_out || !evecs_out || !scratch || N <= 0) return TADMM_ERR_INVALID;
+  if (scratch_bytes < tadmm_eigh_scratch_bytes(N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "eigh scratch too small");
+  hipStream_t s = (hipStream_t)stream_;
+  const int Npad = (int)align_up(N, 2 * kJB), ld = (int)align_up(N, 32), nb = Npad / kJB;
+  char* base = (char*)scratch;
+  size_t off = 0;
+  double* XT = (double*)(base + off); off += align_up((size_t)Npad * ld * 8, 256);
+  EigDesc* edev = (EigDesc*)(base + off); off += align_up(sizeof(EigDesc), 256);
+  BlockRef* m_tick = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
+  BlockRef* m_norm = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
+  BlockRef* m_ext = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
+  off += align_up(Npad * sizeof(BlockRef), 256);
+  double* lam = (double*)(base + off); off += align_up((size_t)Npad * 8, 256);
+  double* sigma = (double*)(base + off); off += align_up((size_t)Npad * 8, 256);
+  int32_t* order = (int32_t*)(base + off); off += align_up((size_t)Npad * 4, 256);
+  double* offs = (double*)(base + off); off += 64;
+  int32_t* done = (int32_t*)(base + off);
+  HIP_OK(h, hipMemsetAsync(XT, 0, (size_t)Npad * ld * 8, s));
+  HIP_OK(h, hipMemcpy2DAsync(XT, (size_t)ld * 8, G, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyDeviceToDevice, s));
+  EigDesc e;
+  memset(&e, 0, sizeof e);
+  e.XT = XT; e.N = N; e.Npad = Npad; e.ld = ld; e.nb = nb; e.off = offs; e.done = done; e.lam = lam; e.order = order;
+  e.sigma = sigma; e.r = N; e.mode = 2; e.out_a = nullptr; e.out_b = nullptr; e.evec_out = evecs_out;
+  std::vector<BlockRef> vt, vn, ve;
+  for (int b = 0; b < nb / 2; ++b) vt.push_back(BlockRef{0, b});
+  for (int b = 0; b < (Npad + 3) / 4; ++b) vn.push_back(BlockRef{0, b});
+  for (int b = 0; b < (N + 3) / 4; ++b) ve.push_back(BlockRef{0, b});
+  HIP_OK(h, hipMemcpyAsync(edev, &e, sizeof e, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(m_tick, vt.data(), vt.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(m_norm, vn.data(), vn.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(m_ext, ve.data(), ve.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipStreamSynchronize(s));
+  launch_jacobi_init(edev, 1, s);
+  const double tol = 1e-9;
+  int tick = 0, gs = 0;
+  bool conv = false;
+  double hoff[3];
+  int hdone = 0;
+  for (; gs < 40 && !conv; ++gs) {
+    for (int t = 0; t < nb - 1; ++t, ++tick) launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 3, s);
+    HIP_OK(h, hipMemcpyAsync(hoff, offs, 24, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipMemcpyAsync(&hdone, done, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipStreamSynchronize(s));
+    conv = hdone || hoff[gs & 1] < tol;
+  }
+  if (sweeps_out) *sweeps_out = gs;
+  if (!conv) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in 40 sweeps");
+  launch_eig_norms(edev, m_norm, (int)vn.size(), s);
+  launch_eig_sort(edev, 1, s);
+  launch_eig_extract(edev, m_ext, (int)ve.size(), s);
+  // eigenvalues in descending order = sigma^2
+  HIP_OK(h, hipGetLastError());
+  // sigma holds sqrt(lambda); square it on the host side of the caller? keep device-only: reuse lam/order
+  // -> evals_out[c] = lam[order[c]] via a tiny gather done with the extract's sigma: sigma^2
+  //    (done by the caller-visible helper below to stay allocation-free)
+  tadmm_square_copy(sigma, evals_out, N, s);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+}  // extern "C"

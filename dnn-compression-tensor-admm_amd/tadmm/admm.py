@@ -1,0 +1,242 @@
+"""ADMM controller with the reference's surface (admm.py:15-149), projection on the MI355X.
+
+Differences a caller can observe (all deliberate):
+  * the projection of ALL layers runs as one grouped plan on the device -- no D2H/H2D round trip
+    (admm.py:50-67) and no per-layer Python loop;
+  * `self.z[name]` is updated in place instead of being re-bound to a new tensor each call;
+  * with `process_group` given, layers are sharded over the ranks (LPT on the SVD cost model) and Z
+    is re-assembled with one all-gather; the reference repeats the full projection on every rank.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, sched, ttd
+from ._cabi import KIND_SVD, KIND_TT_CONV, KIND_TT_LINEAR, TadmmError
+
+
+def _multi(rank_entry) -> bool:
+    return (not isinstance(rank_entry, int)) and len(rank_entry) > 1
+
+
+class _PenaltyFn(torch.autograd.Function):
+    """0.5*rho*sum||W-Z+U||^2 with gradient rho*(W-Z+U) (admm.py:80-85), one fused launch."""
+
+    @staticmethod
+    def forward(ctx, admm, loss, *params):
+        val, grads = admm._penalty_forward(params)
+        ctx.grads = grads
+        ctx.n = len(params)
+        return loss + val.to(loss.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        gs = torch._foreach_mul(ctx.grads, gout.to(ctx.grads[0].dtype)) if ctx.grads else []
+        return (None, gout) + tuple(gs)
+
+
+class ADMM:
+    def __init__(self, model, rho, hp_dict, format, device, verbose=False, log=False, process_group=None):
+        self.model = model
+        self.init_rho = rho
+        self.hp_dict = hp_dict
+        self.format = format
+        self.device = torch.device(device)
+        self.verbose = verbose
+        self.log = log
+        self.process_group = process_group
+        if self.log:
+            self.logger = {}
+        if format == 'none':
+            raise Exception('ERROR: Tensor format should be specified!')      # admm.py:27-28
+        self.rho = self.init_rho
+        self.u: Dict[str, torch.Tensor] = {}
+        self.z: Dict[str, torch.Tensor] = {}
+        for name, param in self.model.named_parameters():                       # admm.py:35-40
+            if name in self.hp_dict.ranks:
+                self.u[name] = torch.zeros(param.shape, dtype=torch.float32, device=self.device)
+                self.z[name] = param.data.detach().clone().to(self.device, torch.float32)
+                if self.log:
+                    self.logger[name] = []
+        self._plan = None
+        self._plan_key = None
+        self._tk_names: List[str] = []
+        self._pen = None
+
+    # ------------------------------------------------------------------ plan construction
+    def _kind_of(self, name, param):
+        ranks = self.hp_dict.ranks[name]
+        if param.dim() == 4:                                                    # admm.py:47-58
+            if self.format == 'tk' and _multi(ranks):
+                return 'tk'
+            if self.format == 'tt' and _multi(ranks):
+                return KIND_TT_CONV
+            return KIND_SVD
+        if param.dim() == 2:                                                    # admm.py:59-68
+            if self.format == 'tk':
+                return 'tk'
+            if self.format == 'tt':
+                return KIND_TT_LINEAR
+            return KIND_SVD
+        raise Exception('ERROR: unsupported layer in ADMM!')                    # admm.py:69
+
+    def _named(self):
+        return [(n, p) for n, p in self.model.named_parameters() if n in self.hp_dict.ranks]
+
+    def _build(self):
+        named = self._named()
+        layers, names, self._tk_names = [], [], []
+        for name, p in named:
+            kind = self._kind_of(name, p)
+            if p.device != self.device or p.dtype != torch.float32 or not p.data.is_contiguous():
+                raise TadmmError(-1, f"{name}: parameters must be contiguous float32 on {self.device}")
+            if kind == 'tk':
+                self._tk_names.append(name)
+                continue
+            entry = dict(kind=kind, W=p.data, U=self.u[name], Z=self.z[name], ranks=self.hp_dict.ranks[name])
+            if kind != KIND_SVD:
+                entry["tt_shapes"] = list(self.hp_dict.tt_shapes[name])
+                entry["ranks"] = list(self.hp_dict.ranks[name])
+            layers.append(entry)
+            names.append(name)
+        self._names = names
+        self._owned = list(range(len(names)))
+        if self.process_group is not None and torch.distributed.get_world_size(self.process_group) > 1:
+            ws = torch.distributed.get_world_size(self.process_group)
+            rk = torch.distributed.get_rank(self.process_group)
+            costs = [sched.layer_cost(L["kind"], list(L["W"].shape), L.get("tt_shapes"), L["ranks"]) for L in layers]
+            parts = sched.lpt_partition(costs, ws)
+            self._parts = parts
+            self._owned = parts[rk]
+        self._plan = ops.ProjectionPlan([layers[i] for i in self._owned]) if self._owned else None
+        if self._plan is not None:
+            # rank clamp side effect: the conv TT path clamps the shared table in place (admm.py:94,97),
+            # the linear path works on a copy (admm.py:105)
+            for j, i in enumerate(self._owned):
+                tbl = self.hp_dict.ranks[names[i]]
+                if layers[i]["kind"] == KIND_TT_CONV and isinstance(tbl, list):
+                    tbl[:] = self._plan.ranks[j]
+        self._plan_key = tuple((n, p.data_ptr()) for n, p in named)
+        if self._tk_names:
+            from . import tucker
+            self._tk = tucker.TuckerProjector(self, self._tk_names)
+
+    # ------------------------------------------------------------------ reference API
+    def update(self, update_u=True):
+        named = self._named()
+        key = tuple((n, p.data_ptr()) for n, p in named)
+        if self._plan_key != key:
+            self._build()
+        resid = {}
+        if self._plan is not None:
+            r = self._plan.run(update_u=update_u, use_u=True)
+            if update_u and (self.log or self.verbose):
+                vals = r.sqrt().cpu().tolist()
+                for j, i in enumerate(self._owned):
+                    resid[self._names[i]] = vals[j]
+        if self._tk_names:
+            resid.update(self._tk.run(update_u))
+        if self.process_group is not None and torch.distributed.get_world_size(self.process_group) > 1:
+            self._exchange(update_u)
+        if update_u:
+            for name, _ in named:                                               # admm.py:75-78
+                if name not in resid:
+                    continue
+                if self.log:
+                    self.logger[name].append(float(resid[name]))
+                if self.verbose:
+                    print('*INFO: {} in ADMM, norm(w-z)={}'.format(name, resid[name]))
+
+    def _exchange(self, update_u):
+        """Sharded mode: broadcast each owner's Z (and U) so every rank holds the full state."""
+        dist = torch.distributed
+        for owner, part in enumerate(self._parts):
+            for i in part:
+                name = self._names[i]
+                dist.broadcast(self.z[name], src=dist.get_global_rank(self.process_group, owner),
+                               group=self.process_group)
+                if update_u:
+                    dist.broadcast(self.u[name], src=dist.get_global_rank(self.process_group, owner),
+                                   group=self.process_group)
+
+    def append_admm_loss(self, loss):
+        params = [p for _, p in self._named()]
+        if not params:
+            return loss
+        return _PenaltyFn.apply(self, loss, *params)
+
+    def adjust_rho(self, epoch, epochs, factor=5):
+        if epoch > int(0.85 * epochs):                                          # admm.py:87-89
+            self.rho = factor * self.init_rho
+
+    # ------------------------------------------------------------------ fused penalty
+    def _penalty_forward(self, params):
+        import ctypes as C
+        names = [n for n, _ in self._named()]
+        n = len(names)
+        dev = self.device
+        key = tuple(p.data_ptr() for p in params)
+        if self._pen is None or self._pen["key"] != key:
+            grads = [torch.empty_like(p.data) for p in params]
+            ptrs = [p.data_ptr() for p in params] + [self.z[k].data_ptr() for k in names] + \
+                   [self.u[k].data_ptr() for k in names] + [g.data_ptr() for g in grads]
+            numel = [p.numel() for p in params]
+            h = ops.Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+            self._pen = dict(key=key, grads=grads, h=h,
+                             ptrs=torch.tensor(ptrs, dtype=torch.int64).to(dev),
+                             numel=torch.tensor(numel, dtype=torch.int64).to(dev), total=int(sum(numel)),
+                             partial=torch.empty(h.lib.tadmm_penalty_scratch_doubles(), dtype=torch.float64,
+                                                 device=dev))
+        pen = self._pen
+        # pointers of z may be unchanged (in-place update) but re-check u/z identity cheaply
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        h = pen["h"]
+        h.check(h.lib.tadmm_penalty(h.ptr, n, pen["ptrs"].data_ptr(), pen["numel"].data_ptr(), pen["total"],
+                                    float(self.rho), float(self.rho), loss.data_ptr(), pen["partial"].data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream))
+        return loss[0], pen["grads"]
+
+    # ------------------------------------------------------------------ per-layer projections (numpy in/out)
+    def _project_np(self, z, kind, tt_shapes, ranks):
+        w = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)).to(self.device)
+        u = torch.zeros_like(w)
+        out = torch.empty_like(w)
+        entry = dict(kind=kind, W=w, U=u, Z=out, ranks=ranks)
+        if tt_shapes is not None:
+            entry["tt_shapes"] = list(tt_shapes)
+        plan = ops.ProjectionPlan([entry])
+        plan.run(update_u=False, use_u=False)
+        return out.cpu().numpy(), plan.ranks[0]
+
+    def prune_conv_rank_tt(self, z, name):                                      # admm.py:91-101
+        tbl = self.hp_dict.ranks[name]
+        out, ranks = self._project_np(z, KIND_TT_CONV, self.hp_dict.tt_shapes[name], list(tbl))
+        if isinstance(tbl, list):
+            tbl[:] = ranks
+        return out
+
+    def prune_linear_rank_tt(self, z, name):                                    # admm.py:103-111
+        out, _ = self._project_np(z, KIND_TT_LINEAR, self.hp_dict.tt_shapes[name], list(self.hp_dict.ranks[name]))
+        return out
+
+    def prune_conv_rank_svd(self, z, name):                                     # admm.py:129-139
+        zz = z.detach().cpu().numpy() if torch.is_tensor(z) else z
+        out, _ = self._project_np(zz, KIND_SVD, None, self.hp_dict.ranks[name])
+        return out.reshape(out.shape[0], out.shape[1], 1, 1)
+
+    def prune_linear_rank_svd(self, z, name):                                   # admm.py:141-149
+        zz = z.detach().cpu().numpy() if torch.is_tensor(z) else z
+        out, _ = self._project_np(zz, KIND_SVD, None, self.hp_dict.ranks[name])
+        return out
+
+    def prune_conv_rank_tk(self, z, name):                                      # admm.py:113-119
+        from . import tucker
+        return tucker.project_numpy(z, self.hp_dict.ranks[name], self.device)
+
+    def prune_linear_rank_tk(self, z, name):                                    # admm.py:121-127
+        from . import tucker
+        return tucker.project_numpy(z, self.hp_dict.ranks[name], self.device)

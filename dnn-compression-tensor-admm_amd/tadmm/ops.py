@@ -1,0 +1,223 @@
+"""Torch-facing wrappers over the C ABI: device memory, streams and pointer plumbing only.
+
+Nothing here computes; every function hands raw device pointers of torch tensors
+to libtadmm_hip.so on the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _cabi
+from ._cabi import (FLAG_SKIP_ROTATIONS, KIND_SVD, KIND_TT_CONV, KIND_TT_LINEAR, GemmDesc, Handle, LayerDesc,
+                    TadmmError, make_layer_desc)
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise TadmmError(-1, f"{what} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32 and what != "G":
+        raise TadmmError(-1, f"{what} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise TadmmError(-1, f"{what} must be contiguous")
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class ProjectionPlan:
+    """Grouped TT/SVD projection of a set of layers (ADMM.update, admm.py:42-78).
+
+    layers: sequence of dicts with keys
+        kind       : KIND_TT_CONV | KIND_TT_LINEAR | KIND_SVD
+        W, U, Z    : float32 device tensors of identical shape (captured by pointer)
+        tt_shapes  : list[int]   (TT kinds)
+        ranks      : list[int] (TT) | int / [int] (SVD)
+    """
+
+    def __init__(self, layers: Sequence[dict], want_cores: bool = False, skip_rotations: bool = True):
+        if not layers:
+            raise ValueError("empty plan")
+        dev = layers[0]["W"].device
+        self.device = dev
+        self.h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        lib = self.h.lib
+        n = len(layers)
+        self.n = n
+        flags = 0 if want_cores or not skip_rotations else FLAG_SKIP_ROTATIONS
+        self._descs = (LayerDesc * n)()
+        self._keep = []
+        Wp = (C.c_void_p * n)()
+        Up = (C.c_void_p * n)()
+        Zp = (C.c_void_p * n)()
+        Cp = (C.c_void_p * n)()
+        self.cores: List[Optional[torch.Tensor]] = [None] * n
+        self._core_shapes = []
+        for i, L in enumerate(layers):
+            for key in ("W", "U", "Z"):
+                _require_cuda(L[key], key)
+                if L[key].shape != L["W"].shape:
+                    raise TadmmError(-1, f"{key} shape differs from W")
+            self._descs[i] = make_layer_desc(L["kind"], list(L["W"].shape), L.get("tt_shapes"), L["ranks"], flags)
+            Wp[i], Up[i], Zp[i] = L["W"].data_ptr(), L["U"].data_ptr(), L["Z"].data_ptr()
+            self._keep.append((L["W"], L["U"], L["Z"]))
+        size = C.c_size_t()
+        self.h.check(lib.tadmm_plan_workspace_bytes(self.h.ptr, n, self._descs, C.byref(size)))
+        # clamped ranks are a pure function of the shapes: compute them to size the core buffers
+        self.ranks = []
+        for i, L in enumerate(layers):
+            d = self._descs[i]
+            if L["kind"] == KIND_SVD:
+                o, k = int(L["W"].shape[0]), int(L["W"].shape[1])
+                r = min(int(d.ranks[0]), o, k)
+                shapes, ranks = [o, k], [1, r, 1]
+            else:
+                shapes = [int(d.tt_shapes[j]) for j in range(d.d)]
+                ranks = _cabi.clamp_ranks(shapes, [int(d.ranks[j]) for j in range(d.d + 1)])
+            self.ranks.append(ranks)
+            self._core_shapes.append([(ranks[j], shapes[j], ranks[j + 1]) for j in range(len(shapes))])
+            if want_cores:
+                tot = sum(a * b * c for a, b, c in self._core_shapes[i])
+                self.cores[i] = torch.empty(tot, dtype=torch.float32, device=dev)
+                Cp[i] = self.cores[i].data_ptr()
+            else:
+                Cp[i] = None
+        self.workspace_bytes = int(size.value)
+        self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=dev)
+        self.resid_sq = torch.zeros(n, dtype=torch.float64, device=dev)
+        self._plan = C.c_void_p()
+        self.h.check(lib.tadmm_plan_create(self.h.ptr, n, self._descs, Wp, Up, Zp, Cp, self.workspace.data_ptr(),
+                                           self.workspace_bytes, C.byref(self._plan)))
+
+    def run(self, update_u: bool = True, use_u: bool = True) -> torch.Tensor:
+        """One projection; returns the device tensor of per-layer ||W-Z||^2 (float64)."""
+        self.h.check(self.h.lib.tadmm_plan_run(self._plan, int(update_u), int(use_u), self.resid_sq.data_ptr(),
+                                               _stream(self.device)))
+        return self.resid_sq
+
+    def enable_timing(self, on=True):
+        self.h.check(self.h.lib.tadmm_plan_enable_timing(self._plan, int(on)))
+
+    def last_timing(self):
+        out = (C.c_double * 8)()
+        self.h.check(self.h.lib.tadmm_plan_last_timing(self._plan, out))
+        keys = ["unfold_ms", "gram_ms", "eig_ms", "project_ms", "reconstruct_ms", "fold_update_ms", "jacobi_sweeps"]
+        return {k: float(out[i]) for i, k in enumerate(keys)}
+
+    def singular_values(self, layer: int, step: int) -> np.ndarray:
+        r = self.ranks[layer][step + 1]
+        out = (C.c_double * r)()
+        self.h.check(self.h.lib.tadmm_plan_singular_values(self._plan, layer, step, out, _stream(self.device)))
+        return np.array(out[:], dtype=np.float64)
+
+    def core_tensors(self, layer: int) -> List[torch.Tensor]:
+        """Views (r_j, n_j, r_{j+1}) into the core buffer of a layer (want_cores=True)."""
+        buf = self.cores[layer]
+        if buf is None:
+            raise TadmmError(-1, "plan was created without cores")
+        out, off = [], 0
+        for a, b, c in self._core_shapes[layer]:
+            out.append(buf[off:off + a * b * c].view(a, b, c))
+            off += a * b * c
+        return out
+
+    def close(self):
+        if getattr(self, "_plan", None) is not None and self._plan:
+            self.h.lib.tadmm_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ grouped GEMM
+def gemm_desc(A, B, Cout, M, N, K, a_strides, b_strides, c_strides, alpha=1.0, beta=0.0, bias_n=None, bias_m=None):
+    g = GemmDesc()
+    g.A, g.B, g.C = A, B, Cout
+    g.M, g.N, g.K = M, N, K
+    g.a_rs, g.a_cs = a_strides
+    g.b_rs, g.b_cs = b_strides
+    g.c_rs, g.c_cs = c_strides
+    g.alpha, g.beta = alpha, beta
+    g.bias_n = bias_n
+    g.bias_m = bias_m
+    return g
+
+
+class GemmBatch:
+    """A packed group of strided GEMMs; `run()` is one kernel launch."""
+
+    def __init__(self, descs: Sequence[GemmDesc], device):
+        self.device = device
+        self.h = Handle.get(device.index if device.index is not None else torch.cuda.current_device())
+        lib = self.h.lib
+        n = len(descs)
+        arr = (GemmDesc * n)(*descs)
+        nbytes = lib.tadmm_gemm_pack_bytes(n, arr)
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else \
+            torch.empty(nbytes, dtype=torch.uint8)
+        nblocks = C.c_int()
+        rc = lib.tadmm_gemm_pack(n, arr, host.data_ptr(), nbytes, C.byref(nblocks))
+        if rc < 0:
+            raise TadmmError(rc, "tadmm_gemm_pack: invalid GEMM descriptor (each operand needs one unit stride)")
+        self.blob = host.to(device, non_blocking=True)
+        self._host = host
+        self.n, self.nblocks = n, int(nblocks.value)
+
+    def run(self):
+        self.h.check(self.h.lib.tadmm_gemm_run(self.h.ptr, self.blob.data_ptr(), self.n, self.nblocks,
+                                               _stream(self.device)))
+
+
+def mm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, alpha=1.0, bias_n=None, bias_m=None):
+    """out = alpha * a @ b (+bias) for 2-D float32 device tensors with arbitrary (one unit) strides."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0]
+    M, K = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    d = gemm_desc(a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(), b.stride(), out.stride(), alpha, 0.0,
+                  None if bias_n is None else bias_n.data_ptr(), None if bias_m is None else bias_m.data_ptr())
+    GemmBatch([d], a.device).run()
+    return out
+
+
+# ------------------------------------------------------------------ Gram / eigh (tests, Tucker)
+def gram(a: torch.Tensor):
+    """fp64 Gram of a float32 (m,n) matrix: A A^T if m<=n else A^T A.  Returns (N,N) float64."""
+    _require_cuda(a, "A")
+    h = Handle.get(a.device.index)
+    lib = h.lib
+    m, n = a.shape
+    npad, ld = C.c_int(), C.c_int()
+    N = lib.tadmm_gram_ld(m, n, C.byref(npad), C.byref(ld))
+    G = torch.empty(npad.value, ld.value, dtype=torch.float64, device=a.device)
+    sb = lib.tadmm_gram_scratch_bytes(m, n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=a.device)
+    h.check(lib.tadmm_gram_f64(h.ptr, a.data_ptr(), m, n, G.data_ptr(), ld.value, scratch.data_ptr(), sb,
+                               _stream(a.device)))
+    return G[:N, :N]
+
+
+def eigh(G: torch.Tensor):
+    """Symmetric PSD eigen-decomposition (descending).  Returns (evals (N,), evecs (N,N) rows, sweeps)."""
+    assert G.dtype == torch.float64 and G.is_cuda and G.dim() == 2 and G.shape[0] == G.shape[1]
+    G = G.contiguous()
+    h = Handle.get(G.device.index)
+    lib = h.lib
+    N = G.shape[0]
+    ev = torch.empty(N, dtype=torch.float64, device=G.device)
+    vec = torch.empty(N, N, dtype=torch.float64, device=G.device)
+    sb = lib.tadmm_eigh_scratch_bytes(N)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=G.device)
+    sweeps = C.c_int()
+    h.check(lib.tadmm_eigh_f64(h.ptr, G.data_ptr(), N, ev.data_ptr(), vec.data_ptr(), scratch.data_ptr(), sb,
+                               C.byref(sweeps), _stream(G.device)))
+    return ev, vec, int(sweeps.value)

@@ -1,0 +1,163 @@
+/*
+ * tadmm.h -- C ABI of the MI355X-native ADMM low-rank projection path.
+ *
+ * The reference (miaoyin390/DNN-Compression-Tensor-ADMM) is pure Python and has
+ * no FFI layer; its boundary for this path is the Python API of admm.py /
+ * ttd.py / TT*.py / TK*.py.  This header is the C ABI
+ * that sits *behind* that Python surface: plain pointers and sizes, no torch
+ * types, extern "C".  Every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - all tensors are row-major contiguous DEVICE pointers (float32 unless said
+ *     otherwise), owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *     call is stream-ordered and asynchronous unless documented otherwise;
+ *   - return value 0 = success, negative = tadmm_status; a human-readable
+ *     message for the last failure of a handle is returned by
+ *     tadmm_last_error();
+ *   - no exceptions cross the boundary; a handle is not thread-safe.
+ */
+#ifndef TADMM_H_
+#define TADMM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TADMM_MAX_MODES 8
+
+typedef enum {
+  TADMM_OK = 0,
+  TADMM_ERR_INVALID = -1,     /* bad argument / inconsistent descriptor          */
+  TADMM_ERR_WORKSPACE = -2,   /* caller workspace too small                      */
+  TADMM_ERR_HIP = -3,         /* a HIP runtime call failed                       */
+  TADMM_ERR_NOCONVERGE = -4,  /* Jacobi eigen-solver hit its sweep cap           */
+  TADMM_ERR_UNSUPPORTED = -5
+} tadmm_status;
+
+typedef enum {
+  TADMM_KIND_TT_CONV = 0,   /* admm.py:91-101  prune_conv_rank_tt  ((O,I,k2)->(O,k2,I) unfold) */
+  TADMM_KIND_TT_LINEAR = 1, /* admm.py:103-111 prune_linear_rank_tt (no permutation)           */
+  TADMM_KIND_SVD = 2,       /* admm.py:129-149 prune_{conv,linear}_rank_svd (2-mode TT)        */
+  TADMM_KIND_TUCKER2 = 3    /* admm.py:113-127 prune_{conv,linear}_rank_tk (HOSVD + HOOI)      */
+} tadmm_kind;
+
+/* flags */
+#define TADMM_FLAG_SKIP_ROTATIONS 1u /* Z-only mode: a TT step whose kept rank equals the row
+                                        count of its unfolding is an orthogonal change of basis
+                                        that cannot change Z; skip its eigen-solve.  Must be 0
+                                        when cores are requested.                              */
+
+/* Plain-old-data description of one compressed parameter. */
+typedef struct {
+  int32_t kind;                      /* tadmm_kind                                        */
+  int32_t ndim;                      /* 2 or 4                                            */
+  int64_t dims[4];                   /* weight shape: (O,I,kh,kw) or (out,in)             */
+  int32_t d;                         /* number of TT modes (TT kinds); 2 for SVD          */
+  int32_t tt_shapes[TADMM_MAX_MODES];/* n_0..n_{d-1}  (hp_dict.tt_shapes[name])           */
+  int32_t ranks[TADMM_MAX_MODES + 1];/* r_0..r_d      (hp_dict.ranks[name]); Tucker: [r_out,r_in] */
+  uint32_t flags;
+  int32_t hooi_max_iter;             /* Tucker only (tensorly default 100)                */
+  float hooi_tol;                    /* Tucker only (tensorly default 1e-4)               */
+} tadmm_layer_desc;
+
+typedef struct tadmm_ctx_s* tadmm_handle;
+typedef struct tadmm_plan_s* tadmm_plan;
+
+/* ---- library / handle ------------------------------------------------- */
+int tadmm_version(void);
+int tadmm_create(int device, tadmm_handle* out);
+int tadmm_destroy(tadmm_handle h);
+const char* tadmm_last_error(tadmm_handle h);
+
+/* ---- rank clamp (ttd.py:18-19) ---------------------------------------- */
+/* The reference clamps r_{i+1} to the number of singular values of the i-th
+ * unfolding, min(r_i*n_i, prod(n_{i+1..})) -- a pure function of the shapes.
+ * Applies it to desc->ranks in place (host only, no device work); returns the
+ * number of entries changed.  Rank selection is therefore bit-exact by
+ * construction. */
+int tadmm_tt_clamp_ranks(tadmm_layer_desc* desc);
+
+/* ---- projection plan: Z <- proj(W+U), U += W-Z, ||W-Z||^2 -------------- */
+/* Replaces ADMM.update (admm.py:42-78) for a set of layers that are processed
+ * together, phase by phase, in grouped launches.  Pointers are captured at
+ * creation; descriptors (with clamped ranks) are copied.
+ *   W[i], U[i], Z[i] : device float32, prod(dims) elements each
+ *   cores[i]         : NULL, or device float32 buffer receiving the TT cores
+ *                      back to back (core_0 .. core_{d-1}, each (r_j,n_j,r_{j+1}));
+ *                      for Tucker: core (r_out,r_in,k2...) then U_out (O,r_out)
+ *                      then U_in (I,r_in)
+ *   workspace        : device scratch of at least tadmm_plan_workspace_bytes */
+int tadmm_plan_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, size_t* bytes);
+int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs,
+                      const float* const* W, float* const* U, float* const* Z, float* const* cores,
+                      void* workspace, size_t workspace_bytes, tadmm_plan* out);
+/* Runs one ADMM projection over all layers of the plan.
+ *   update_u     : 0 -> only Z is written (ADMM.__init__ + update(update_u=False), engines.py:245)
+ *   use_u        : 0 -> project W alone (the --decompose path: TTConv.py:96-109, TTLinear.py:61-66)
+ *   resid_sq_dev : NULL or device double[n_layers]  <- ||W-Z||_2^2 per layer (admm.py:73-76)
+ * The call synchronises the stream once per Jacobi sweep (convergence poll). */
+int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream);
+/* Singular values kept at TT step `step` of layer `layer` in the last run (device->host copy,
+ * synchronous).  out must hold ranks[step+1] doubles. */
+int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_host, void* stream);
+/* Per-phase device time of the last run in milliseconds:
+ * [0]=unfold [1]=gram [2]=eig [3]=project [4]=reconstruct [5]=fold/update, [6]=jacobi sweeps (count) */
+int tadmm_plan_last_timing(tadmm_plan p, double out_ms[8]);
+int tadmm_plan_enable_timing(tadmm_plan p, int on);
+/* clamped ranks of a layer (r_0..r_d); returns d+1 */
+int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
+int tadmm_plan_destroy(tadmm_plan p);
+
+/* ---- augmented-Lagrangian penalty (admm.py:80-85) ---------------------- */
+/* loss_dev[0] += 0.5*rho*sum_i ||W_i - Z_i + U_i||^2 ; gradW[i] (nullable) = grad_scale*(W_i-Z_i+U_i)
+ * (grad_scale = rho * upstream gradient of the scalar loss).
+ * ptrs_dev: device array of 4*n pointers laid out [W_0..W_{n-1} | Z.. | U.. | gradW..] ;
+ * numel_dev: device int64[n]; partial_dev: device double scratch >= tadmm_penalty_scratch_doubles(). */
+int tadmm_penalty_scratch_doubles(void);
+int tadmm_penalty(tadmm_handle h, int n, const void* const* ptrs_dev, const int64_t* numel_dev,
+                  int64_t total_numel, float rho, float grad_scale, double* loss_dev, double* partial_dev,
+                  void* stream);
+
+/* ---- building blocks (also used by the factorised layers) -------------- */
+/* C[i,j] = alpha * sum_k A(i,k) B(k,j) (+ beta*C) with arbitrary element strides; one of the two
+ * strides of each operand must be 1.  Replaces the torch.mm / F.linear chains of
+ * TTLinear.py:79-86, TTConv.py:133-147, TKConv.py:210-214, TKLinear.py:66-71 and np.dot of
+ * ttd.py:39-40.  fp32 in, fp32 MFMA accumulate. */
+typedef struct {
+  const float* A; const float* B; float* C;
+  int32_t M, N, K;
+  int64_t a_rs, a_cs, b_rs, b_cs, c_rs, c_cs;
+  float alpha, beta;
+  const float* bias_n;   /* nullable: added along N (C[i,j] += bias_n[j]) */
+  const float* bias_m;   /* nullable: added along M */
+} tadmm_gemm_desc;
+/* pack: writes GemmDesc[n] + block map into a host blob the caller uploads (and may cache) itself;
+ * run: launches one grouped kernel over the uploaded blob. */
+size_t tadmm_gemm_pack_bytes(int n, const tadmm_gemm_desc* descs);
+int tadmm_gemm_pack(int n, const tadmm_gemm_desc* descs, void* blob_host, size_t blob_bytes, int* nblocks_out);
+int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, void* stream);
+
+/* G = A A^T (m<=n) or A^T A (m>n) of a row-major float32 m x n matrix, exact fp32 products
+ * accumulated in fp64 on v_mfma_f64_16x16x4_f64.  G is written as double[Npad][ldg] (zero padded; see tadmm_gram_ld), N=min(m,n).
+ * partial_dev: scratch of tadmm_gram_scratch_bytes(m,n). */
+size_t tadmm_gram_scratch_bytes(int m, int n);
+/* returns N=min(m,n); *Npad rows and *ld doubles per row of the G image */
+int tadmm_gram_ld(int m, int n, int* Npad, int* ld);
+int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int ldg,
+                   void* partial_dev, size_t partial_bytes, void* stream);
+
+/* Symmetric eigen-decomposition of double[N][N] G (row-major, symmetric PSD) by one-sided block
+ * Jacobi.  evals_out: double[N] descending; evecs_out: double[N][N], row j = eigenvector j.
+ * Synchronous (polls convergence).  scratch: tadmm_eigh_scratch_bytes(N). */
+size_t tadmm_eigh_scratch_bytes(int N);
+int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, double* evecs_out,
+                   void* scratch_dev, size_t scratch_bytes, int* sweeps_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TADMM_H_ */

@@ -1,0 +1,84 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against numpy/torch fp64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (75, 1024, 256), (130, 33, 77), (1, 5, 3), (105, 4608, 480),
+                                   (257, 129, 65)])
+@pytest.mark.parametrize("ta,tb,tc", [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1), (0, 0, 1)])
+def test_gemm_strided(dev, M, N, K, ta, tb, tc):
+    from tadmm import ops
+    a = _rand((K, M) if ta else (M, K), 1, dev)
+    b = _rand((N, K) if tb else (K, N), 2, dev)
+    av = a.t() if ta else a
+    bv = b.t() if tb else b
+    out = torch.empty((N, M) if tc else (M, N), device=dev)
+    ov = out.t() if tc else out
+    ops.mm(av, bv, out=ov)
+    ref = av.double() @ bv.double()
+    err = (ov.double() - ref).abs().max().item()
+    scale = (av.double().abs() @ bv.double().abs()).max().item()
+    assert err <= 4e-7 * scale, (err, scale)   # fp32 fma chain, K <= 480
+
+
+def test_gemm_bias_alpha(dev):
+    from tadmm import ops
+    a, b = _rand((70, 40), 3, dev), _rand((40, 90), 4, dev)
+    bn, bm = _rand((90,), 5, dev), _rand((70,), 6, dev)
+    out = ops.mm(a, b, alpha=0.5, bias_n=bn, bias_m=bm)
+    ref = 0.5 * (a.double() @ b.double()) + bn.double()[None, :] + bm.double()[:, None]
+    assert (out.double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("m,n", [(8, 4608), (32, 73728), (120, 1152), (75, 1024), (130, 2048), (240, 2304),
+                                 (576, 64), (945, 512), (1024, 256), (17, 33), (33, 17), (5, 5)])
+def test_gram_fp64_exact_products(dev, m, n):
+    from tadmm import ops
+    a = _rand((m, n), 10 + m, dev)
+    G = ops.gram(a).cpu().numpy()
+    a64 = a.cpu().numpy().astype(np.float64)
+    ref = a64 @ a64.T if m <= n else a64.T @ a64
+    assert G.shape == ref.shape
+    # products are exact, only the fp64 summation order differs
+    np.testing.assert_allclose(G, ref, rtol=0, atol=1e-12 * np.abs(ref).max() * max(1, np.log2(max(m, n))))
+    assert np.array_equal(G, G.T)   # bitwise symmetric by construction
+
+
+@pytest.mark.parametrize("N", [5, 16, 30, 75, 130, 256, 300])
+@pytest.mark.parametrize("kind", ["gauss", "decay"])
+def test_eigh_jacobi(dev, N, kind):
+    from tadmm import ops
+    rng = np.random.default_rng(N)
+    if kind == "gauss":
+        a = rng.standard_normal((N, 3 * N))
+    else:
+        q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+        a = q * np.exp(-6.0 * np.arange(N) / N)
+    G = a @ a.T
+    G = 0.5 * (G + G.T)
+    ev, vec, sweeps = ops.eigh(torch.from_numpy(G).to(dev))
+    ev, vec = ev.cpu().numpy(), vec.cpu().numpy()
+    ref = np.linalg.eigvalsh(G)[::-1]
+    np.testing.assert_allclose(ev, ref, rtol=0, atol=1e-12 * ref[0])
+    assert np.all(np.diff(ev) <= 0)
+    # residual and orthonormality of the leading half (the part the TT truncation uses)
+    k = max(1, N // 2)
+    V = vec[:k]
+    np.testing.assert_allclose(V @ V.T, np.eye(k), atol=1e-10)
+    R = G @ V.T - V.T * ev[:k]
+    assert np.abs(R).max() <= 1e-10 * ref[0]
+    assert sweeps <= 30, sweeps
