@@ -54,7 +54,7 @@ void launch_gram_reduce(const GramDesc* descs_dev, const BlockRef* map_dev, int 
 constexpr int kJB = 8;          // columns per block; a pair is 2*kJB = 16 columns = one MFMA tile
 struct EigDesc {
   double* XT;         // [Npad][ld]: row j holds column j of X (starts as G, converges to G*V)
-  int32_t N, Npad, ld, nb;       // nb = Npad / kJB (even)
+  int32_t N, Npad, ld, nb;       // nb = Npad / kJB (multiple of 4)
   double* off;        // [3]: [0],[1] max relative off-diagonal per sweep parity; [2] max squared column norm
   int32_t* done;      // [1] sticky convergence flag
   // finalize outputs
@@ -69,8 +69,13 @@ struct EigDesc {
   double* evec_out;   // optional: [r][N] eigenvectors as rows in fp64 (tadmm_eigh_f64), nullable
 };
 void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s);
+size_t jacobi_tick_lds_bytes(int ld_max);    // dynamic LDS of a tick1 launch whose largest problem has row length ld_max
+size_t jacobi_tick2_lds_bytes(int ld_max);   // same for the LDS-resident super-pair kernel
+bool jacobi_tick2_fits(int ld_max);
+// super=false: one workgroup per pair of 8-column blocks (nb/2 per problem, nb-1 ticks per sweep)
+// super=true : one workgroup per pair of 16-column super-blocks (nb/4 per problem, nb/2-1 ticks per sweep)
 void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
-                        int inner_sweeps, hipStream_t s);
+                        int inner_sweeps, size_t lds_bytes, bool super, hipStream_t s);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
 void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s);
 void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);

@@ -6,21 +6,31 @@
 // convergence X = G*V has orthogonal columns whose norms are the eigenvalues and whose directions are
 // the eigenvectors (x_j = lambda_j v_j).
 //
-// Blocking: columns are grouped in blocks of kJB = 8; a *pair* of blocks = 16 columns = exactly one
-// 16x16 fp64 MFMA tile.  One launch ("tick") processes nb/2 disjoint block pairs, one workgroup each,
-// following a round-robin tournament so that after nb-1 ticks every pair of blocks has met once (one
-// sweep).  Per pair and tick:
-//   1. H = Xp^T Xp  (16x16 Gram of the pair's columns over all N rows)        -- v_mfma_f64_16x16x4
-//   2. a few cyclic two-sided Jacobi sweeps on H accumulate the 16x16 rotation Q (one wave, LDS)
-//   3. Xp <- Xp * Q                                                             -- v_mfma_f64_16x16x4
-// Pairs never share columns, so a tick needs no inter-workgroup communication; the kernel boundary is
-// the only global synchronisation.  X is stored transposed (XT[j][:] = column j, contiguous) so every
-// access is a coalesced row segment.
+// Blocking.  Columns are grouped in blocks of kJB = 8; a *pair* of blocks = 16 columns = exactly one
+// 16x16 fp64 MFMA tile.  A pair visit does
+//   1. H = Xp^T Xp  (16x16 Gram of the pair's columns over all rows)           -- v_mfma_f64_16x16x4
+//   2. one cyclic sweep of two-sided Jacobi on H accumulating the 16x16 rotation Q (one wave, LDS)
+//   3. Xp <- Xp * Q                                                              -- v_mfma_f64_16x16x4
+// X is stored transposed (XT[j][:] = column j, contiguous) so every access is a row segment.
 //
-// Convergence: every pair visit records max |h_ab|/sqrt(h_aa h_bb) *before* rotating into a per-problem
-// slot (double compared as integer, values are >= 0).  A problem is converged when a whole sweep saw
-// nothing above `tol`; Jacobi converges quadratically, so tol = 1e-9 leaves ~1e-16 after that sweep.
+// Two launch shapes ("ticks"), both following a round-robin tournament so that after a sweep every pair
+// of blocks has met exactly once; the kernel boundary is the only global synchronisation:
+//   tick2 (ld <= 512): a workgroup owns a *super-pair* of two 16-column super-blocks (32 columns, 128 KiB
+//          of LDS), loads it once, runs the 2 rounds of 2 concurrent sub-pair visits (4 waves each) that
+//          cover its 4 cross sub-pairs entirely in LDS, and stores it once -- half the launches and half
+//          the HBM/Infinity-Cache traffic of tick1 per sweep;
+//   tick1 (any ld):   a workgroup owns one pair (16 columns).
+// Index pairs inside a block (tick1) / inside a super-block (tick2) are rotated on the first tick of a
+// sweep only, when every (super-)block is in exactly one pair.
+//
+// Convergence.  Every pair visit records, *before* rotating, max_ij |h_ij| / (sqrt(h_ii h_jj) * w_ij) with
+// w_ij = max(1, 1e-14/tol * lambda_max/min(lambda_i, lambda_j)): columns with small eigenvalues carry fp64
+// rounding noise of relative size ~eps*lambda_max/lambda and cannot be orthogonalised beyond it, so their
+// target scales accordingly (exactly low-rank inputs would otherwise never terminate).  A problem is
+// converged when a whole sweep saw nothing above `tol`; Jacobi converges quadratically, so tol = 1e-9
+// leaves ~1e-16 after that sweep.
 #include "common.h"
+#include <cstdio>
 
 namespace tadmm {
 
@@ -28,29 +38,24 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kPair = 2 * kJB;  // 16
+constexpr int kHP = kPair + 1;  // padded leading dimension of the 16x16 LDS images
 
 __global__ __launch_bounds__(256) void jacobi_init_kernel(const EigDesc* __restrict__ descs) {
   const EigDesc d = descs[blockIdx.x];
-  if (threadIdx.x == 0) {
-    d.off[0] = 1.0; d.off[1] = 1.0;
-    *d.done = 0;
-  }
-  // scale reference for "numerically null column": max squared column norm of the initial X = G
+  // scale reference: squared column norms of X = G are >= G_jj^2, so the largest diagonal entry squared
+  // is a cheap lower bound of the largest squared column norm (= lambda_max^2 at convergence)
   __shared__ double red[4];
   double mx = 0.0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < d.N; j += 4) {
-    double s = 0.0;
-    const double* row = d.XT + (int64_t)j * d.ld;
-    for (int i = lane; i < d.N; i += 64) s += row[i] * row[i];
+  for (int j = threadIdx.x; j < d.N; j += 256) mx = fmax(mx, fabs(d.XT[(int64_t)j * d.ld + j]));
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    s = __shfl(s, 0, 64);
-    mx = fmax(mx, s);
-  }
-  if (lane == 0) red[wave] = mx;
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) d.off[2] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (threadIdx.x == 0) {
+    const double g = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    d.off[0] = 1.0; d.off[1] = 1.0; d.off[2] = g * g;
+    *d.done = 0;
+  }
 }
 
 __device__ __forceinline__ void rr_pair(int nb, int step, int q, int& a, int& b) {
@@ -60,16 +65,145 @@ __device__ __forceinline__ void rr_pair(int nb, int step, int q, int& a, int& b)
   else { a = (step + q) % m; b = (step - q + m) % m; }
 }
 
+// LDS ordering inside ONE wave: the hardware executes a wave's LDS instructions in order, so data
+// written by some lanes is visible to the other lanes of the same wave at the next instruction; the
+// fence only stops the compiler from caching LDS values in registers / reordering across it.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// Scratch of one pair visit (all in LDS)
+struct PairScratch {
+  double* red;            // [4][256] cross-wave partials of H
+  double (*H)[kHP];       // [16][17]
+  double (*Q)[kHP];       // [16][17]
+  double* cA; double* cB; // [16] rotation coefficients per index
+  int* pt;                // [16] partner index
+  int* rotated;           // [1]
+};
+constexpr int kPairScratchDoubles = 4 * 256 + 2 * kPair * kHP + 2 * kPair + kPair / 2 + 2;
+
+__device__ __forceinline__ PairScratch carve_scratch(double* base) {
+  PairScratch s;
+  s.red = base;
+  s.H = reinterpret_cast<double (*)[kHP]>(base + 4 * 256);
+  s.Q = s.H + kPair;
+  s.cA = reinterpret_cast<double*>(s.Q + kPair);
+  s.cB = s.cA + kPair;
+  s.pt = reinterpret_cast<int*>(s.cB + kPair);
+  s.rotated = s.pt + kPair;
+  return s;
+}
+
+// H partial of one wave: rows `lrow(r)` of the LDS slab, columns [i0, i1) (multiple of 8 long)
+__device__ __forceinline__ void pair_gram_partial(const double* __restrict__ Xs, int ldp, int lrow_r, int i0, int i1,
+                                                  int q, double* __restrict__ red_w, int lane) {
+  const double* row = Xs + lrow_r * ldp;
+  double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  for (int i = i0; i < i1; i += 8) {
+    const double2_t v = *reinterpret_cast<const double2_t*>(row + i + 2 * q);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red_w[lane * 4 + e] = acc0[e] + acc1[e];
+}
+
+// 256 threads (t = 0..255) fold the 4 wave partials into H and reset Q = I
+__device__ __forceinline__ void pair_gram_reduce(const PairScratch& S, int t) {
+  const int l = t >> 2, reg = t & 3;
+  const int hr = (l >> 4) + 4 * reg, hc = l & 15;
+  S.H[hr][hc] = (S.red[t] + S.red[256 + t]) + (S.red[512 + t] + S.red[768 + t]);
+  S.Q[hr][hc] = (hr == hc) ? 1.0 : 0.0;
+}
+
+// One wave: convergence measure + one cyclic sweep of two-sided Jacobi on H (accumulating Q).
+//   within: also rotate the 2 x 28 index pairs inside each block of 8 (15 parallel steps instead of 8)
+// Returns the measure (same value on all lanes); sets *S.rotated.
+__device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lane, double hmax, double tol,
+                                                   bool within, int inner_sweeps) {
+  double (*Hs)[kHP] = S.H;
+  double (*Qs)[kHP] = S.Q;
+  const double floor2 = hmax * 1e-28;                 // lambda < 1e-14 lambda_max: padding / exact zeros
+  const double wscale = 1e-14 / tol;
+  double mx = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = lane * 4 + k;
+    const int i = e >> 4, j = e & 15;
+    if (i < j) {
+      const double hii = Hs[i][i], hjj = Hs[j][j];
+      const double hmin = fmin(hii, hjj);
+      if (hmin > floor2) {
+        const double w = fmax(1.0, wscale * sqrt(hmax / hmin));   // lambda_max / lambda_min of the pair
+        mx = fmax(mx, fabs(Hs[i][j]) * rsqrt(hii * hjj) / w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  mx = __shfl(mx, 0, 64);
+  int did = 0;
+  if (mx > 1e-15) {
+    // rotation schedule: the 8x8 = 64 cross-block pairs in 8 parallel steps (i, 8 + (i+st)%8); then,
+    // if `within`, 7 steps of round robin inside each block (lanes 0-3 block A, 4-7 block B)
+    const int nsteps = within ? (kJB + kJB - 1) : kJB;
+    for (int isw = 0; isw < inner_sweeps; ++isw) {
+      for (int st = 0; st < nsteps; ++st) {
+        if (lane < kPair / 2) {
+          int p, qq;
+          if (st < kJB) { p = lane; qq = kJB + ((lane + st) & (kJB - 1)); }
+          else {
+            int a2, b2;
+            rr_pair(kJB, st - kJB, lane & 3, a2, b2);
+            const int base = (lane >> 2) * kJB;
+            p = base + min(a2, b2); qq = base + max(a2, b2);
+          }
+          const double hpp = Hs[p][p], hqq = Hs[qq][qq], hpq = Hs[p][qq];
+          double c = 1.0, s = 0.0;
+          if (hpq * hpq > 1e-36 * fabs(hpp * hqq) && fabs(hpq) > 1e-300) {
+            // t = 2 hpq sgn(z) / (|z| + sqrt(z^2 + 4 hpq^2)),  z = hqq - hpp   (small-angle root)
+            const double z = hqq - hpp;
+            const double den = fabs(z) + sqrt(z * z + 4.0 * hpq * hpq);
+            const double t = (z >= 0.0 ? 2.0 : -2.0) * hpq / den;
+            c = rsqrt(1.0 + t * t);
+            s = t * c;
+            did = 1;
+          }
+          // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
+          S.cA[p] = c; S.cB[p] = -s; S.pt[p] = qq;
+          S.cA[qq] = c; S.cB[qq] = s; S.pt[qq] = p;
+        }
+        wave_lds_fence();
+        double nh[4], nq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = lane * 4 + k;
+          const int i = e >> 4, j = e & 15;
+          const int is = S.pt[i], js = S.pt[j];
+          const double ai = S.cA[i], bi = S.cB[i], aj = S.cA[j], bj = S.cB[j];
+          nh[k] = ai * (aj * Hs[i][j] + bj * Hs[i][js]) + bi * (aj * Hs[is][j] + bj * Hs[is][js]);
+          nq[k] = aj * Qs[i][j] + bj * Qs[i][js];
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = lane * 4 + k;
+          Hs[e >> 4][e & 15] = nh[k];
+          Qs[e >> 4][e & 15] = nq[k];
+        }
+        wave_lds_fence();
+      }
+    }
+    did = __any(did);
+  }
+  if (lane == 0) *S.rotated = did;
+  return mx;
+}
+
+// Dynamic LDS layout of tick1 (doubles): X[16][ldp] | PairScratch
 __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restrict__ descs,
                                                           const BlockRef* __restrict__ map, int tick, double tol,
                                                           int inner_sweeps) {
-  __shared__ double red[4][256];
-  __shared__ double Hs[kPair][kPair + 1];
-  __shared__ double Qs[kPair][kPair + 1];
-  __shared__ double coefA[kPair], coefB[kPair];
-  __shared__ int partner[kPair];
-  __shared__ int rotated;
-
+  extern __shared__ __attribute__((aligned(16))) double smem[];
   const BlockRef br = map[blockIdx.x];
   const EigDesc d = descs[br.prob];
   if (*d.done) return;
@@ -84,141 +218,178 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
       return;
     }
   }
+  const int ld = d.ld, ldp = ld + 2;
+  double* Xs = smem;
+  const PairScratch S = carve_scratch(Xs + kPair * ldp);
+
   int ba, bb;
   rr_pair(nb, step, br.local, ba, bb);
   const int r = lane & 15, q = lane >> 4;
-  const int ld = d.ld;
-  // MFMA row r of the pair -> row of XT
-  const int myrow = (r < kJB) ? (ba * kJB + r) : (bb * kJB + (r - kJB));
   double* __restrict__ XT = d.XT;
 
-  // ---- 1. H = Xp^T Xp : each wave reduces a quarter of the rows of X (= columns of XT) ----
+  // ---- 0. stage the pair's 16 columns (rows of XT) in LDS: one burst of 16-byte loads ----
   {
-    const int per = ld >> 2;                       // ld is a multiple of 32 -> per % 8 == 0
-    const int i0 = wave * per, i1 = i0 + per;
-    const double* row = XT + (int64_t)myrow * ld;
-    double4_t acc = {0, 0, 0, 0};
-    for (int i = i0; i < i1; i += 8) {
-      const double2_t v = *reinterpret_cast<const double2_t*>(row + i + 2 * q);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, acc, 0, 0, 0);
+    const int c2n = ld >> 1;                       // double2 chunks per row
+    const int total = kPair * c2n;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += 256) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
+      const double2_t v = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
+      *reinterpret_cast<double2_t*>(Xs + row * ldp + 2 * c2) = v;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
   }
-  if (tid == 0) rotated = 0;
   __syncthreads();
   // every thread has taken its convergence decision by now: safe to clear the slot of the NEXT sweep
   if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
-  {
-    const int l = tid >> 2, reg = tid & 3;
-    const int hr = (l >> 4) + 4 * reg, hc = l & 15;
-    Hs[hr][hc] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    Qs[hr][hc] = (hr == hc) ? 1.0 : 0.0;
-  }
-  __syncthreads();
 
-  // ---- 2. inner two-sided Jacobi on the 16x16 H, one wave, LDS resident ----
+  const int per = ld >> 2;                         // ld is a multiple of 32 -> per % 8 == 0
+  pair_gram_partial(Xs, ldp, r, wave * per, (wave + 1) * per, q, S.red + wave * 256, lane);
+  __syncthreads();
+  pair_gram_reduce(S, tid);
+  __syncthreads();
   if (wave == 0) {
-    volatile double (*H)[kPair + 1] = Hs;
-    volatile double (*Q)[kPair + 1] = Qs;
-    volatile double* cA = coefA;
-    volatile double* cB = coefB;
-    volatile int* pt = partner;
-    const double nullfloor = d.off[2] * 1e-26;
-    // convergence measure before rotating
-    double mx = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = lane * 4 + k;
-      const int i = e >> 4, j = e & 15;
-      if (i < j) {
-        const double hii = H[i][i], hjj = H[j][j];
-        if (hii > nullfloor && hjj > nullfloor) mx = fmax(mx, fabs(H[i][j]) / sqrt(hii * hjj));
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
-    if (lane == 0) {
-      atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]),
-                (unsigned long long)__double_as_longlong(mx));
-    }
-    mx = __shfl(mx, 0, 64);
-    if (mx > 1e-15) {
-      int did = 0;
-      for (int isw = 0; isw < inner_sweeps; ++isw) {
-        for (int st = 0; st < kPair - 1; ++st) {
-          if (lane < kPair / 2) {
-            int p, qq;
-            rr_pair(kPair, st, lane, p, qq);
-            if (p > qq) { const int t = p; p = qq; qq = t; }
-            const double hpp = H[p][p], hqq = H[qq][qq], hpq = H[p][qq];
-            double c = 1.0, s = 0.0;
-            if (fabs(hpq) > 1e-18 * sqrt(fabs(hpp * hqq)) && fabs(hpq) > 1e-300) {
-              const double tau = (hqq - hpp) / (2.0 * hpq);
-              const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-              c = 1.0 / sqrt(1.0 + t * t);
-              s = t * c;
-              did = 1;
-            }
-            // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
-            cA[p] = c; cB[p] = -s; pt[p] = qq;
-            cA[qq] = c; cB[qq] = s; pt[qq] = p;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          double nh[4], nq[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int e = lane * 4 + k;
-            const int i = e >> 4, j = e & 15;
-            const int is = pt[i], js = pt[j];
-            const double ai = cA[i], bi = cB[i], aj = cA[j], bj = cB[j];
-            nh[k] = ai * (aj * H[i][j] + bj * H[i][js]) + bi * (aj * H[is][j] + bj * H[is][js]);
-            nq[k] = aj * Q[i][j] + bj * Q[i][js];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int e = lane * 4 + k;
-            H[e >> 4][e & 15] = nh[k];
-            Q[e >> 4][e & 15] = nq[k];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-      }
-      did = __any(did);
-      if (lane == 0) rotated = did;
-    }
+    const double mx = pair_inner_solve(S, lane, d.off[2], tol, step == 0, inner_sweeps);
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mx));
   }
   __syncthreads();
-  if (!rotated) return;
+  if (!*S.rotated) return;
 
-  // ---- 3. Xp <- Xp * Q, i.e. rows of XT:  Y[a][:] = sum_b Q[b][a] * XT[row(b)][:]  ----
+  // ---- 3. Xp <- Xp * Q, i.e. rows of XT:  Y[a][:] = sum_b Q[b][a] * X[b][:]  ----
   {
     double qa[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) qa[t] = Qs[4 * t + q][r];      // A operand: A[m=a][k=b] = Q[b][a]
-    int rowk[4];
+    for (int t = 0; t < 4; ++t) qa[t] = S.Q[4 * t + q][r];     // A operand: A[m=a][k=b] = Q[b][a]
+    int64_t orow[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int b = 4 * t + q;
-      rowk[t] = (b < kJB) ? (ba * kJB + b) : (bb * kJB + (b - kJB));
+    for (int e = 0; e < 4; ++e) {
+      const int a = q + 4 * e;                                  // D row = (l>>4) + 4*reg
+      orow[e] = (int64_t)((a < kJB) ? (ba * kJB + a) : (bb * kJB + (a - kJB))) * ld;
     }
     const int ntile = ld >> 4;
     for (int it = wave; it < ntile; it += 4) {
       const int col = it * 16 + r;
       double4_t acc = {0, 0, 0, 0};
-      double bv[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) bv[t] = XT[(int64_t)rowk[t] * ld + col];   // B[k=b][n=i]
+      for (int t = 0; t < 4; ++t)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], Xs[(4 * t + q) * ldp + col], acc, 0, 0, 0);   // B[k=b][n=i]
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], bv[t], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) XT[orow[e] + col] = acc[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tick2: one workgroup (512 threads) = one super-pair of 2 x 16 columns, LDS resident.
+// Dynamic LDS (doubles): X[32][ldp] | PairScratch[2]
+// Sub-blocks of 8 rows in the slab: 0,1 = super-block A ; 2,3 = super-block B.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSuper = 2 * kPair;   // 32 rows in the slab
+
+__global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __restrict__ descs,
+                                                           const BlockRef* __restrict__ map, int tick, double tol,
+                                                           int inner_sweeps) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const BlockRef br = map[blockIdx.x];
+  const EigDesc d = descs[br.prob];
+  if (*d.done) return;
+  const int nbs = d.nb >> 1;                       // super-blocks of 16 columns
+  const int steps = nbs - 1;
+  const int sweep = tick / steps;
+  const int step = tick - sweep * steps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = wave >> 2, wv = wave & 3, th = tid & 255;
+  if (step == 0 && sweep > 0) {
+    if (d.off[(sweep - 1) & 1] < tol) {
+      if (br.local == 0 && tid == 0) *d.done = 1;
+      return;
+    }
+  }
+  const int ld = d.ld, ldp = ld + 2;
+  double* Xs = smem;
+  const PairScratch S = carve_scratch(Xs + kSuper * ldp + half * kPairScratchDoubles);
+
+  int sa, sb;
+  rr_pair(nbs, step, br.local, sa, sb);
+  const int r = lane & 15, q = lane >> 4;
+  double* __restrict__ XT = d.XT;
+
+  // ---- load the 32 columns once ----
+  {
+    const int c2n = ld >> 1;
+    const int total = kSuper * c2n;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += 512) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
+      const double2_t v = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
+      *reinterpret_cast<double2_t*>(Xs + row * ldp + 2 * c2) = v;
+    }
+  }
+  __syncthreads();
+  if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
+
+  const double hmax = d.off[2];
+  const int per = ld >> 2;
+  double mxall = 0.0;
+  int any_rot = 0;
+  // rounds: (first tick of a sweep only) inside the super-blocks: (0,1) | (2,3) incl. the pairs inside
+  //         each block of 8;   round 1: (0,2) | (1,3);   round 2: (0,3) | (1,2)
+  const int first_round = (step == 0) ? 0 : 1;
+  for (int round = first_round; round < 3; ++round) {
+    int u, v;
+    if (round == 0) { u = half ? 2 : 0; v = half ? 3 : 1; }
+    else if (round == 1) { u = half ? 1 : 0; v = half ? 3 : 2; }
+    else { u = half ? 1 : 0; v = half ? 2 : 3; }
+    const int lrow_r = (r < kJB) ? (u * kJB + r) : (v * kJB + (r - kJB));
+    pair_gram_partial(Xs, ldp, lrow_r, wv * per, (wv + 1) * per, q, S.red + wv * 256, lane);
+    __syncthreads();
+    pair_gram_reduce(S, th);
+    __syncthreads();
+    if (wv == 0) {
+      const double mx = pair_inner_solve(S, lane, hmax, tol, round == 0, inner_sweeps);
+      mxall = fmax(mxall, mx);
+    }
+    __syncthreads();
+    if (*S.rotated) {
+      any_rot = 1;
+      double qa[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int a = q + 4 * e;                                           // D row = (l>>4) + 4*reg
-        const int orow = (a < kJB) ? (ba * kJB + a) : (bb * kJB + (a - kJB));
-        XT[(int64_t)orow * ld + col] = acc[e];
+      for (int t = 0; t < 4; ++t) qa[t] = S.Q[4 * t + q][r];
+      int rowk[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {       // k = 4t+q (B operand row) and D row q+4e share this map
+        const int b = 4 * t + q;
+        rowk[t] = ((b < kJB) ? (u * kJB + b) : (v * kJB + (b - kJB))) * ldp;
       }
+      const int ntile = ld >> 4;
+      for (int it = wv; it < ntile; it += 4) {
+        const int col = it * 16 + r;
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], Xs[rowk[t] + col], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Xs[rowk[e] + col] = acc[e];   // in place: this tile is touched by this wave only
+      }
+    }
+    __syncthreads();
+  }
+  if (wv == 0 && lane == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mxall));
+  // ---- store back (skipped when nothing rotated in this workgroup) ----
+  any_rot = __syncthreads_or(any_rot);
+  if (!any_rot) return;
+  {
+    const int c2n = ld >> 1;
+    const int total = kSuper * c2n;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += 512) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
+      *reinterpret_cast<double2_t*>(XT + (int64_t)grow * ld + 2 * c2) =
+          *reinterpret_cast<const double2_t*>(Xs + row * ldp + 2 * c2);
     }
   }
 }
@@ -302,10 +473,36 @@ void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s) {
   if (nprob <= 0) return;
   hipLaunchKernelGGL(jacobi_init_kernel, dim3(nprob), dim3(256), 0, s, descs_dev);
 }
+
+size_t jacobi_tick_lds_bytes(int ld_max) { return ((size_t)kPair * (ld_max + 2) + kPairScratchDoubles) * 8; }
+size_t jacobi_tick2_lds_bytes(int ld_max) { return ((size_t)kSuper * (ld_max + 2) + 2 * kPairScratchDoubles) * 8; }
+bool jacobi_tick2_fits(int ld_max) { return jacobi_tick2_lds_bytes(ld_max) <= 160 * 1024; }
+
 void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
-                        int inner_sweeps, hipStream_t s) {
+                        int inner_sweeps, size_t lds_bytes, bool super, hipStream_t s) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(jacobi_tick_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, tick, tol, inner_sweeps);
+  static bool attr_set = false;
+  if (!attr_set) {   // allow the full 160 KiB of a CU as dynamic LDS (default cap is 64 KiB)
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick2_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess || e2 != hipSuccess)
+      fprintf(stderr, "[tadmm] hipFuncSetAttribute(max dynamic LDS): %s / %s\n", hipGetErrorString(e1),
+              hipGetErrorString(e2));
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  if (super)
+    hipLaunchKernelGGL(jacobi_tick2_kernel, dim3(nblocks), dim3(512), lds_bytes, s, descs_dev, map_dev, tick, tol,
+                       inner_sweeps);
+  else
+    hipLaunchKernelGGL(jacobi_tick_kernel, dim3(nblocks), dim3(256), lds_bytes, s, descs_dev, map_dev, tick, tol,
+                       inner_sweeps);
+  hipError_t e = hipPeekAtLastError();
+  if (e != hipSuccess)
+    fprintf(stderr, "[tadmm] jacobi tick launch failed: %s (blocks=%d lds=%zu super=%d)\n", hipGetErrorString(e),
+            nblocks, lds_bytes, (int)super);
 }
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
   if (nblocks <= 0) return;

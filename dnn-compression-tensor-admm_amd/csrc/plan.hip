@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -127,8 +128,7 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     st.trans = (int64_t)st.m > st.cols;
     st.N = (int)std::min<int64_t>(st.m, st.cols);
     st.skip = (d.flags & TADMM_FLAG_SKIP_ROTATIONS) && !st.trans && st.r == st.m;
-    const int blk2 = 2 * kJB;
-    st.Npad = (int)align_up(st.N, blk2);
+    st.Npad = (int)align_up(st.N, 4 * kJB);     // whole super-pairs of 2 x 16 columns
     st.nb = st.Npad / kJB;
     st.ld = (int)align_up(st.N, 32);
     st.nt = (st.N + 31) / 32;
@@ -156,6 +156,9 @@ struct StepPlan {
   size_t eig_desc_off = 0;
   int neig = 0;
   int gsteps = 0;                 // ticks per global sweep = max(nb-1)
+  size_t tick_lds = 0;            // dynamic LDS of the tick launches of this step
+  bool super = false;             // LDS-resident super-pair kernel (all problems of the level fit)
+  int ld_max = 0;
   size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
   std::vector<int> nb;            // per problem
   std::vector<int> layer_of;      // problem -> layer
@@ -185,7 +188,8 @@ struct tadmm_plan_s {
   std::vector<double> h_off;
   std::vector<int> h_done;
   double tol = 1e-9;
-  int inner_sweeps = 3;
+  int inner_sweeps = 1;
+  bool debug = false;
   int max_global_sweeps = 40;
 };
 
@@ -286,16 +290,55 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
   P->resid_partial_off = ar.take((size_t)smap.size() * 8);
 
   // ---- TT steps ----
+  // Levels: layer l runs its TT step s at level s + lvl_off[l].  The longest chains fix the number of
+  // levels; shorter chains are shifted so that their eigen-solves share a level with problems of at
+  // least their size (a level costs ~ (nb_max - 1) ticks per sweep whatever its population), on the
+  // least populated such level -- e.g. ResNet-50: the 1x1 convs' single N=256/512 solve runs beside the
+  // 3x3 convs' N=480/512 steps instead of beside their N<=32 first step.
   int maxsteps = 0;
   for (const LayerGeom& g : P->layers) maxsteps = std::max(maxsteps, (int)g.steps.size());
+  std::vector<int> lvl_off(n, 0);
+  {
+    std::vector<int> lvl_nb(maxsteps, 0);
+    std::vector<long> lvl_wgs(maxsteps, 0);
+    std::vector<int> order(n);
+    for (int l = 0; l < n; ++l) order[l] = l;
+    auto heavy = [&](int l) { int m = 0; for (const StepGeom& st : P->layers[l].steps) if (!st.skip) m = std::max(m, st.nb); return m; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      const size_t ca = P->layers[a].steps.size(), cb = P->layers[b].steps.size();
+      if (ca != cb) return ca > cb;
+      return heavy(a) > heavy(b);
+    });
+    for (int l : order) {
+      const LayerGeom& g = P->layers[l];
+      const int len = (int)g.steps.size();
+      int best = 0; double best_cost = 1e300;
+      for (int off = 0; off + len <= maxsteps; ++off) {
+        // cost = added ticks (levels whose nb_max grows) first, then population of the touched levels
+        double cost = 0;
+        for (int s = 0; s < len; ++s) {
+          if (g.steps[s].skip) continue;
+          const int lv = off + s;
+          cost += 1e6 * std::max(0, g.steps[s].nb - lvl_nb[lv]) + (double)lvl_wgs[lv] * g.steps[s].nb;
+        }
+        if (cost < best_cost) { best_cost = cost; best = off; }
+      }
+      lvl_off[l] = best;
+      for (int s = 0; s < len; ++s) {
+        if (g.steps[s].skip) continue;
+        lvl_nb[best + s] = std::max(lvl_nb[best + s], g.steps[s].nb);
+        lvl_wgs[best + s] += g.steps[s].nb / 2;
+      }
+    }
+  }
   P->steps.assign(maxsteps, StepPlan());
   // recon chain bookkeeping: for each layer the list of (core ptr, m, r, cols) of non-skipped steps
   struct RecOp { const float* core; int m, r; int64_t cols; };
   std::vector<std::vector<RecOp>> recops(n);
   std::vector<const float*> lastT(n, nullptr);
 
-  for (int s = 0; s < maxsteps; ++s) {
-    StepPlan& sp = P->steps[s];
+  for (int lev = 0; lev < maxsteps; ++lev) {
+    StepPlan& sp = P->steps[lev];
     std::vector<GramDesc> gd;
     std::vector<EigDesc> ed;
     std::vector<GemmDesc> pd;
@@ -303,7 +346,8 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     std::vector<int> layer_of;
     for (int l = 0; l < n; ++l) {
       const LayerGeom& g = P->layers[l];
-      if (s >= (int)g.steps.size()) continue;
+      const int s = lev - lvl_off[l];
+      if (s < 0 || s >= (int)g.steps.size()) continue;
       const StepGeom& st = g.steps[s];
       if (st.skip) {   // identity: T_{s+1} aliases T_s, no core
         if (cores && cores[l]) CTX_FAIL(h, TADMM_ERR_INVALID, "TADMM_FLAG_SKIP_ROTATIONS is incompatible with cores output");
@@ -319,6 +363,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     for (int p = 0; p < sp.neig; ++p) {
       const int l = layer_of[p];
       const LayerGeom& g = P->layers[l];
+      const int s = lev - lvl_off[l];
       const StepGeom& st = g.steps[s];
       const bool last_step = (s + 2 == g.d);
       // core storage
@@ -371,8 +416,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       e.evec_out = nullptr;
       ed.push_back(e);
       sp.nb.push_back(st.nb);
-      sp.gsteps = std::max(sp.gsteps, st.nb - 1);
-      for (int b = 0; b < st.nb / 2; ++b) m_tick.push_back(BlockRef{p, b});
+      sp.ld_max = std::max(sp.ld_max, st.ld);
       for (int b = 0; b < (st.Npad + 3) / 4; ++b) m_norm.push_back(BlockRef{p, b});
       for (int b = 0; b < (st.r + 3) / 4; ++b) m_ext.push_back(BlockRef{p, b});
       // projection GEMM
@@ -414,6 +458,16 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     sp.gram_r.map_off = da.take(std::max<size_t>(m_gr.size() * sizeof(BlockRef), 16));
     sp.gram_r.nblocks = (int)m_gr.size();
     if (img && !m_gr.empty()) img->put(sp.gram_r.map_off, m_gr.data(), m_gr.size() * sizeof(BlockRef));
+    // tick shape of the level: LDS-resident super-pairs when every problem fits, else plain pairs
+    sp.super = sp.neig > 0 && jacobi_tick2_fits(sp.ld_max) && !getenv("TADMM_NO_SUPER");
+    sp.tick_lds = sp.super ? jacobi_tick2_lds_bytes(sp.ld_max) : jacobi_tick_lds_bytes(sp.ld_max);
+    sp.gsteps = 0;
+    for (int pq = 0; pq < sp.neig; ++pq) {
+      const int units = sp.super ? sp.nb[pq] / 2 : sp.nb[pq];     // players of the tournament
+      sp.nb[pq] = units;
+      sp.gsteps = std::max(sp.gsteps, units - 1);
+      for (int b = 0; b < units / 2; ++b) m_tick.push_back(BlockRef{pq, b});
+    }
     place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m_tick);
     sp.eig_desc_off = sp.eig_tick.desc_off;
     sp.eig_norm = sp.eig_tick;
@@ -582,6 +636,9 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
     hipError_t e = hipMemcpy(P->ws, img.bytes.data(), img.bytes.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "descriptor upload failed: %s", hipGetErrorString(e)); }
   }
+  if (const char* e = getenv("TADMM_JACOBI_TOL")) P->tol = atof(e);
+  if (getenv("TADMM_DEBUG")) P->debug = true;
+  if (const char* e = getenv("TADMM_JACOBI_INNER")) P->inner_sweeps = atoi(e);
   size_t maxe = 1;
   for (const StepPlan& sp : P->steps) maxe = std::max<size_t>(maxe, sp.neig);
   P->h_off.resize(maxe * 3);
@@ -616,13 +673,13 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
   double acc_ms[8] = {0};
   int total_sweeps = 0;
   // timing helper: record a pair of events around a phase and accumulate after a sync
-  auto tic = [&](int i) { if (p->timing) hipEventRecord(p->ev[i], s); };
+  auto tic = [&](int i) { if (p->timing) (void)hipEventRecord(p->ev[i], s); };
   auto toc = [&](int i, int slot) {
     if (!p->timing) return;
-    hipEventRecord(p->ev[i + 1], s);
-    hipEventSynchronize(p->ev[i + 1]);
+    (void)hipEventRecord(p->ev[i + 1], s);
+    (void)hipEventSynchronize(p->ev[i + 1]);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+    (void)hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
     acc_ms[slot] += ms;
   };
 
@@ -648,7 +705,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     for (; gs < p->max_global_sweeps && !all_done; ++gs) {
       for (int t = 0; t < sp.gsteps; ++t, ++tick)
         launch_jacobi_tick(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
-                           p->inner_sweeps, s);
+                           p->inner_sweeps, sp.tick_lds, sp.super, s);
       HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipStreamSynchronize(s));
@@ -665,6 +722,13 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
       }
     }
     total_sweeps += gs;
+    if (p->debug) {
+      (void)hipStreamSynchronize(s);
+      int nbmax = 0, nbig = 0; long wgs = sp.eig_tick.nblocks;
+      for (int q = 0; q < sp.neig; ++q) { nbmax = std::max(nbmax, sp.nb[q]); nbig += sp.nb[q] >= 32; }
+      fprintf(stderr, "[tadmm] step: neig=%d (nb>=32: %d) nbmax=%d ticks/sweep=%d wgs/tick=%ld sweeps=%d ticks=%d lds=%zu\n",
+              sp.neig, nbig, nbmax, sp.gsteps, wgs, gs, tick, sp.tick_lds);
+    }
     if (!all_done) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in %d sweeps", p->max_global_sweeps);
     launch_eig_norms(ed, (const BlockRef*)D(sp.eig_norm.map_off), sp.eig_norm.nblocks, s);
     launch_eig_sort(ed, sp.neig, s);
@@ -704,8 +768,16 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
 
 int tadmm_plan_destroy(tadmm_plan p) {
   if (!p) return TADMM_OK;
-  if (p->ev_made) for (auto& e : p->ev) hipEventDestroy(e);
+  if (p->ev_made) for (auto& e : p->ev) (void)hipEventDestroy(e);
   delete p;
+  return TADMM_OK;
+}
+
+int tadmm_plan_set_jacobi(tadmm_plan p, double tol, int inner_sweeps, int max_sweeps) {
+  if (!p) return TADMM_ERR_INVALID;
+  if (tol > 0) p->tol = tol;
+  if (inner_sweeps > 0) p->inner_sweeps = inner_sweeps;
+  if (max_sweeps > 0) p->max_global_sweeps = max_sweeps;
   return TADMM_OK;
 }
 
@@ -772,7 +844,7 @@ int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, voi
 static void gram_geom(int m, int n, StepGeom& st) {
   st.m = m; st.cols = n; st.trans = m > n;
   st.N = std::min(m, n);
-  st.Npad = (int)align_up(st.N, 2 * kJB);
+  st.Npad = (int)align_up(st.N, 4 * kJB);
   st.nb = st.Npad / kJB;
   st.ld = (int)align_up(st.N, 32);
   st.nt = (st.N + 31) / 32;
@@ -836,7 +908,7 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
 }
 
 size_t tadmm_eigh_scratch_bytes(int N) {
-  const size_t Npad = align_up(N, 2 * kJB), ld = align_up(N, 32);
+  const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, 32);
   return align_up(Npad * ld * 8, 256) + align_up(sizeof(EigDesc), 256) + 4 * align_up(Npad * sizeof(BlockRef), 256) +
          align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024;
 }
@@ -846,7 +918,10 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   if (!h || !G || !evals_out || !evecs_out || !scratch || N <= 0) return TADMM_ERR_INVALID;
   if (scratch_bytes < tadmm_eigh_scratch_bytes(N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "eigh scratch too small");
   hipStream_t s = (hipStream_t)stream_;
-  const int Npad = (int)align_up(N, 2 * kJB), ld = (int)align_up(N, 32), nb = Npad / kJB;
+  const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, 32), nb = Npad / kJB;
+  const bool super = jacobi_tick2_fits(ld) && !getenv("TADMM_NO_SUPER");
+  const int units = super ? nb / 2 : nb;
+  const size_t tick_lds = super ? jacobi_tick2_lds_bytes(ld) : jacobi_tick_lds_bytes(ld);
   char* base = (char*)scratch;
   size_t off = 0;
   double* XT = (double*)(base + off); off += align_up((size_t)Npad * ld * 8, 256);
@@ -867,7 +942,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   e.XT = XT; e.N = N; e.Npad = Npad; e.ld = ld; e.nb = nb; e.off = offs; e.done = done; e.lam = lam; e.order = order;
   e.sigma = sigma; e.r = N; e.mode = 2; e.out_a = nullptr; e.out_b = nullptr; e.evec_out = evecs_out;
   std::vector<BlockRef> vt, vn, ve;
-  for (int b = 0; b < nb / 2; ++b) vt.push_back(BlockRef{0, b});
+  for (int b = 0; b < units / 2; ++b) vt.push_back(BlockRef{0, b});
   for (int b = 0; b < (Npad + 3) / 4; ++b) vn.push_back(BlockRef{0, b});
   for (int b = 0; b < (N + 3) / 4; ++b) ve.push_back(BlockRef{0, b});
   HIP_OK(h, hipMemcpyAsync(edev, &e, sizeof e, hipMemcpyHostToDevice, s));
@@ -882,7 +957,8 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   double hoff[3];
   int hdone = 0;
   for (; gs < 40 && !conv; ++gs) {
-    for (int t = 0; t < nb - 1; ++t, ++tick) launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 3, s);
+    for (int t = 0; t < units - 1; ++t, ++tick)
+      launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 1, tick_lds, super, s);
     HIP_OK(h, hipMemcpyAsync(hoff, offs, 24, hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipMemcpyAsync(&hdone, done, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipStreamSynchronize(s));

@@ -99,6 +99,9 @@ class ProjectionPlan:
                                                _stream(self.device)))
         return self.resid_sq
 
+    def set_jacobi(self, tol=0.0, inner_sweeps=0, max_sweeps=0):
+        self.h.check(self.h.lib.tadmm_plan_set_jacobi(self._plan, float(tol), int(inner_sweeps), int(max_sweeps)))
+
     def enable_timing(self, on=True):
         self.h.check(self.h.lib.tadmm_plan_enable_timing(self._plan, int(on)))
 

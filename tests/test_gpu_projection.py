@@ -210,10 +210,10 @@ def test_projection_properties_resnet50(dev):
     for k in z1:
         rel = float((a.z[k] - z1[k]).norm() / z1[k].norm())
         assert rel <= 2e-6, (k, rel)
-    # a 1x1 layer's Z has rank <= r (checked with the device Gram + eigen-solver itself)
-    from tadmm import ops
+    # a 1x1 layer's Z has rank <= r (independent check: LAPACK on the host)
     k = "layer4.0.conv3.weight"
-    zz = z1[k].reshape(z1[k].shape[0], -1)
-    ev, _, _ = ops.eigh(ops.gram(zz).contiguous())
+    zz = z1[k].reshape(z1[k].shape[0], -1).cpu().numpy().astype(np.float64)
+    sv = np.linalg.svd(zz, compute_uv=False)
     r = hp.ranks[k][1]
-    assert float(ev[r]) <= 1e-10 * float(ev[0])
+    assert sv[r] <= 1e-5 * sv[0], (sv[r], sv[0])
+    assert sv[r - 1] >= 1e-2 * sv[0]
