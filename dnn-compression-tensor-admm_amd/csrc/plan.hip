@@ -563,6 +563,12 @@ extern "C" {
 
 int tadmm_version(void) { return 100; }
 
+int tadmm_abi_sizes(int* layer_desc_bytes, int* gemm_desc_bytes) {
+  if (layer_desc_bytes) *layer_desc_bytes = (int)sizeof(tadmm_layer_desc);
+  if (gemm_desc_bytes) *gemm_desc_bytes = (int)sizeof(tadmm_gemm_desc);
+  return TADMM_OK;
+}
+
 int tadmm_create(int device, tadmm_handle* out) {
   if (!out) return TADMM_ERR_INVALID;
   int count = 0;

@@ -1,0 +1,6 @@
+"""Drop-in alias of the reference module `ttd.py`: re-exports the MI355X-native implementation."""
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from tadmm.ttd import ten2tt, tt2ten  # noqa: E402,F401

@@ -59,6 +59,7 @@ class GemmDesc(C.Structure):
 # name -> (restype, argtypes); this table IS the list of symbols include/tadmm.h declares
 ABI = {
     "tadmm_version": (C.c_int, []),
+    "tadmm_abi_sizes": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tadmm_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "tadmm_destroy": (C.c_int, [C.c_void_p]),
     "tadmm_last_error": (C.c_char_p, [C.c_void_p]),
@@ -123,6 +124,11 @@ def load():
             fn.argtypes = args
         if missing:
             raise TadmmLibraryError(f"{path} does not export: {', '.join(missing)}")
+        a, b = C.c_int(), C.c_int()
+        lib.tadmm_abi_sizes(C.byref(a), C.byref(b))
+        if (a.value, b.value) != (C.sizeof(LayerDesc), C.sizeof(GemmDesc)):
+            raise TadmmLibraryError(f"{path}: struct layout mismatch (library {a.value}/{b.value} bytes, "
+                                    f"binding {C.sizeof(LayerDesc)}/{C.sizeof(GemmDesc)})")
         _lib = lib
         return lib
 

@@ -113,13 +113,14 @@ class ADMM:
             self._parts = parts
             self._owned = parts[rk]
         self._plan = ops.ProjectionPlan([layers[i] for i in self._owned]) if self._owned else None
-        if self._plan is not None:
-            # rank clamp side effect: the conv TT path clamps the shared table in place (admm.py:94,97),
-            # the linear path works on a copy (admm.py:105)
-            for j, i in enumerate(self._owned):
-                tbl = self.hp_dict.ranks[names[i]]
-                if layers[i]["kind"] == KIND_TT_CONV and isinstance(tbl, list):
-                    tbl[:] = self._plan.ranks[j]
+        # rank clamp side effect: the conv TT path clamps the shared table in place (admm.py:94,97), the
+        # linear path works on a copy (admm.py:105).  The clamp is a pure function of the shapes, so every
+        # rank applies it to every layer, owned or not.
+        from ._cabi import clamp_ranks
+        for i, L in enumerate(layers):
+            tbl = self.hp_dict.ranks[names[i]]
+            if L["kind"] == KIND_TT_CONV and isinstance(tbl, list):
+                tbl[:] = clamp_ranks(L["tt_shapes"], list(tbl))
         self._plan_key = tuple((n, p.data_ptr()) for n, p in named)
         if self._tk_names:
             from . import tucker

@@ -69,6 +69,8 @@ typedef struct tadmm_plan_s* tadmm_plan;
 
 /* ---- library / handle ------------------------------------------------- */
 int tadmm_version(void);
+/* sizeof(tadmm_layer_desc) / sizeof(tadmm_gemm_desc) as compiled: lets a foreign binding verify its struct layout */
+int tadmm_abi_sizes(int* layer_desc_bytes, int* gemm_desc_bytes);
 int tadmm_create(int device, tadmm_handle* out);
 int tadmm_destroy(tadmm_handle h);
 const char* tadmm_last_error(tadmm_handle h);
