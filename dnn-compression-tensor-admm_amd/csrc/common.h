@@ -76,6 +76,14 @@ bool jacobi_tick2_fits(int ld_max);
 // super=true : one workgroup per pair of 16-column super-blocks (nb/4 per problem, nb/2-1 ticks per sweep)
 void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, size_t lds_bytes, bool super, hipStream_t s);
+void dump_stamps();
+// register/LDS-resident cross phase (jacobi_cross.hip) + its once-per-sweep companion (tick1 in self mode)
+size_t jacobi_cross_lds_bytes(int ld_max);
+int jacobi_cross_max_ld();
+void launch_jacobi_cross(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
+                         int ld_max, hipStream_t s);
+void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
+                        int inner_sweeps, int ld_max, hipStream_t s);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
 void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s);
 void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);

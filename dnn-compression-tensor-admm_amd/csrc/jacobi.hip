@@ -123,6 +123,7 @@ __device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lan
   double (*Hs)[kHP] = S.H;
   double (*Qs)[kHP] = S.Q;
   const double floor2 = hmax * 1e-28;                 // lambda < 1e-14 lambda_max: padding / exact zeros
+  const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;   // keeps the fp32 angle estimate in range
   const double wscale = 1e-14 / tol;
   double mx = 0.0;
 #pragma unroll
@@ -160,11 +161,27 @@ __device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lan
           const double hpp = Hs[p][p], hqq = Hs[qq][qq], hpq = Hs[p][qq];
           double c = 1.0, s = 0.0;
           if (hpq * hpq > 1e-36 * fabs(hpp * hqq) && fabs(hpq) > 1e-300) {
-            // t = 2 hpq sgn(z) / (|z| + sqrt(z^2 + 4 hpq^2)),  z = hqq - hpp   (small-angle root)
-            const double z = hqq - hpp;
-            const double den = fabs(z) + sqrt(z * z + 4.0 * hpq * hpq);
-            const double t = (z >= 0.0 ? 2.0 : -2.0) * hpq / den;
-            c = rsqrt(1.0 + t * t);
+            // tan(theta) of the small-angle root, t = w sgn(z) / (|z| + sqrt(z^2 + w^2)), z = hqq-hpp, w = 2hpq.
+            // Only the *orthogonality* of the rotation must be exact: t is estimated in fp32 (the pair is
+            // annihilated to ~1e-7 relative, i.e. >= 7 more digits per sweep -- the quadratic phase is not
+            // slowed), then c = (1+t^2)^-1/2 is refined to fp64 so that c^2 + s^2 = 1 to rounding.
+            const float zf = (float)((hqq - hpp) * inv_hmax), wf = (float)(2.0 * hpq * inv_hmax);
+            const float az = fabsf(zf), aw = fabsf(wf);
+            float tf;
+            if (az >= aw) {
+              const float u = wf * __builtin_amdgcn_rcpf(az);                 // |u| <= 1
+              tf = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + u * u));
+            } else {
+              const float v = az * __builtin_amdgcn_rcpf(aw);                 // v < 1
+              tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
+            }
+            if (zf < 0.0f) tf = -tf;
+            const double t = (double)tf;
+            const double x = 1.0 + t * t;                                     // in [1, 2]
+            double y = __builtin_amdgcn_rsq(x);
+            y = y * (1.5 - 0.5 * x * y * y);
+            y = y * (1.5 - 0.5 * x * y * y);
+            c = y;
             s = t * c;
             did = 1;
           }
@@ -202,12 +219,15 @@ __device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lan
 // Dynamic LDS layout of tick1 (doubles): X[16][ldp] | PairScratch
 __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restrict__ descs,
                                                           const BlockRef* __restrict__ map, int tick, double tol,
-                                                          int inner_sweeps) {
+                                                          int inner_sweeps, int self_mode) {
+  // self_mode: companion of jacobi_cross_kernel.  The tournament runs over nb/2 super-blocks of 16
+  // columns; this kernel acts only on the first tick of a sweep, one workgroup per super-block, and
+  // rotates all 120 index pairs inside it (blocks 2*local and 2*local+1, `within` rotations included).
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const BlockRef br = map[blockIdx.x];
   const EigDesc d = descs[br.prob];
   if (*d.done) return;
-  const int nb = d.nb;
+  const int nb = self_mode ? (d.nb >> 1) : d.nb;
   const int steps = nb - 1;
   const int sweep = tick / steps;
   const int step = tick - sweep * steps;
@@ -218,12 +238,14 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
       return;
     }
   }
+  if (self_mode && step != 0) return;
   const int ld = d.ld, ldp = ld + 2;
   double* Xs = smem;
   const PairScratch S = carve_scratch(Xs + kPair * ldp);
 
   int ba, bb;
-  rr_pair(nb, step, br.local, ba, bb);
+  if (self_mode) { ba = 2 * br.local; bb = ba + 1; }
+  else rr_pair(nb, step, br.local, ba, bb);
   const int r = lane & 15, q = lane >> 4;
   double* __restrict__ XT = d.XT;
 
@@ -241,7 +263,8 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   }
   __syncthreads();
   // every thread has taken its convergence decision by now: safe to clear the slot of the NEXT sweep
-  if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
+  // (in self mode the cross kernel of the same tick does it)
+  if (!self_mode && step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
 
   const int per = ld >> 2;                         // ld is a multiple of 32 -> per % 8 == 0
   pair_gram_partial(Xs, ldp, r, wave * per, (wave + 1) * per, q, S.red + wave * 256, lane);
@@ -287,6 +310,13 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
 // ------------------------------------------------------------------------------------------------
 constexpr int kSuper = 2 * kPair;   // 32 rows in the slab
 
+#ifdef TADMM_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && tid == 0) g_stamps[i] += clock64() - t0; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __restrict__ descs,
                                                            const BlockRef* __restrict__ map, int tick, double tol,
                                                            int inner_sweeps) {
@@ -307,6 +337,10 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
     }
   }
   const int ld = d.ld, ldp = ld + 2;
+#ifdef TADMM_STAMPS
+  const unsigned long long t0 = clock64();
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) g_stamps[31] += 1;
+#endif
   double* Xs = smem;
   const PairScratch S = carve_scratch(Xs + kSuper * ldp + half * kPairScratchDoubles);
 
@@ -328,6 +362,7 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
     }
   }
   __syncthreads();
+  STAMP(0);
   if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
 
   const double hmax = d.off[2];
@@ -345,13 +380,16 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
     const int lrow_r = (r < kJB) ? (u * kJB + r) : (v * kJB + (r - kJB));
     pair_gram_partial(Xs, ldp, lrow_r, wv * per, (wv + 1) * per, q, S.red + wv * 256, lane);
     __syncthreads();
+    STAMP(1 + 4 * round);
     pair_gram_reduce(S, th);
     __syncthreads();
+    STAMP(2 + 4 * round);
     if (wv == 0) {
       const double mx = pair_inner_solve(S, lane, hmax, tol, round == 0, inner_sweeps);
       mxall = fmax(mxall, mx);
     }
     __syncthreads();
+    STAMP(3 + 4 * round);
     if (*S.rotated) {
       any_rot = 1;
       double qa[4];
@@ -375,6 +413,7 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
       }
     }
     __syncthreads();
+    STAMP(4 + 4 * round);
   }
   if (wv == 0 && lane == 0)
     atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mxall));
@@ -392,7 +431,22 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
           *reinterpret_cast<const double2_t*>(Xs + row * ldp + 2 * c2);
     }
   }
+  STAMP(20);
 }
+
+#ifdef TADMM_STAMPS
+void dump_stamps() {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return;
+  const double n = h[31] ? (double)h[31] : 1.0;
+  fprintf(stderr, "[stamps] launches=%llu  cumulative cycles/launch: load=%.0f", h[31], h[0] / n);
+  for (int r = 0; r < 3; ++r)
+    fprintf(stderr, " | r%d gram=%.0f red=%.0f inner=%.0f upd=%.0f", r, h[1 + 4 * r] / n, h[2 + 4 * r] / n, h[3 + 4 * r] / n, h[4 + 4 * r] / n);
+  fprintf(stderr, " | end=%.0f\n", h[20] / n);
+}
+#else
+void dump_stamps() {}
+#endif
 
 // ---- finalize: eigenvalues = column norms, descending order, scaled eigenvectors ----
 __global__ __launch_bounds__(256) void eig_norms_kernel(const EigDesc* __restrict__ descs,
@@ -478,6 +532,20 @@ size_t jacobi_tick_lds_bytes(int ld_max) { return ((size_t)kPair * (ld_max + 2) 
 size_t jacobi_tick2_lds_bytes(int ld_max) { return ((size_t)kSuper * (ld_max + 2) + 2 * kPairScratchDoubles) * 8; }
 bool jacobi_tick2_fits(int ld_max) { return jacobi_tick2_lds_bytes(ld_max) <= 160 * 1024; }
 
+void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
+                        int inner_sweeps, int ld_max, hipStream_t s) {
+  if (nblocks <= 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(jacobi_tick_kernel, dim3(nblocks), dim3(256), jacobi_tick_lds_bytes(ld_max), s, descs_dev, map_dev,
+                     tick, tol, inner_sweeps, 1);
+}
+
 void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, size_t lds_bytes, bool super, hipStream_t s) {
   if (nblocks <= 0) return;
@@ -498,7 +566,7 @@ void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int n
                        inner_sweeps);
   else
     hipLaunchKernelGGL(jacobi_tick_kernel, dim3(nblocks), dim3(256), lds_bytes, s, descs_dev, map_dev, tick, tol,
-                       inner_sweeps);
+                       inner_sweeps, 0);
   hipError_t e = hipPeekAtLastError();
   if (e != hipSuccess)
     fprintf(stderr, "[tadmm] jacobi tick launch failed: %s (blocks=%d lds=%zu super=%d)\n", hipGetErrorString(e),

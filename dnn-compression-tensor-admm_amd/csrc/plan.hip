@@ -130,7 +130,8 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     st.skip = (d.flags & TADMM_FLAG_SKIP_ROTATIONS) && !st.trans && st.r == st.m;
     st.Npad = (int)align_up(st.N, 4 * kJB);     // whole super-pairs of 2 x 16 columns
     st.nb = st.Npad / kJB;
-    st.ld = (int)align_up(st.N, 32);
+    // row length of the eigen-solver's X image: 1 KiB chunks for the register-resident cross kernel
+    st.ld = (int)align_up(st.N, st.N <= jacobi_cross_max_ld() ? 128 : 32);
     st.nt = (st.N + 31) / 32;
     const int64_t K = st.trans ? st.m : st.cols;
     const int ntp = st.nt * (st.nt + 1) / 2;
@@ -158,6 +159,8 @@ struct StepPlan {
   int gsteps = 0;                 // ticks per global sweep = max(nb-1)
   size_t tick_lds = 0;            // dynamic LDS of the tick launches of this step
   bool super = false;             // LDS-resident super-pair kernel (all problems of the level fit)
+  int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 2: register/LDS cross kernel + self
+  Phase eig_self;                 // mode 2: block map of the once-per-sweep self kernel (nb/2 workgroups per problem)
   int ld_max = 0;
   size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
   std::vector<int> nb;            // per problem
@@ -459,16 +462,29 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     sp.gram_r.nblocks = (int)m_gr.size();
     if (img && !m_gr.empty()) img->put(sp.gram_r.map_off, m_gr.data(), m_gr.size() * sizeof(BlockRef));
     // tick shape of the level: LDS-resident super-pairs when every problem fits, else plain pairs
-    sp.super = sp.neig > 0 && jacobi_tick2_fits(sp.ld_max) && !getenv("TADMM_NO_SUPER");
-    sp.tick_lds = sp.super ? jacobi_tick2_lds_bytes(sp.ld_max) : jacobi_tick_lds_bytes(sp.ld_max);
+    {
+      const char* em = getenv("TADMM_JACOBI_MODE");
+      int want = em ? atoi(em) : 1;
+      if (want == 2 && (sp.ld_max > jacobi_cross_max_ld() || sp.ld_max % 128)) want = 1;
+      if (want == 1 && !jacobi_tick2_fits(sp.ld_max)) want = 0;
+      sp.mode = sp.neig > 0 ? want : 0;
+    }
+    sp.super = sp.mode >= 1;
+    sp.tick_lds = sp.mode == 1 ? jacobi_tick2_lds_bytes(sp.ld_max) : jacobi_tick_lds_bytes(sp.ld_max);
     sp.gsteps = 0;
+    std::vector<BlockRef> m_self;
     for (int pq = 0; pq < sp.neig; ++pq) {
       const int units = sp.super ? sp.nb[pq] / 2 : sp.nb[pq];     // players of the tournament
       sp.nb[pq] = units;
       sp.gsteps = std::max(sp.gsteps, units - 1);
       for (int b = 0; b < units / 2; ++b) m_tick.push_back(BlockRef{pq, b});
+      if (sp.mode == 2) for (int b = 0; b < units; ++b) m_self.push_back(BlockRef{pq, b});
     }
     place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m_tick);
+    sp.eig_self = sp.eig_tick;
+    sp.eig_self.map_off = da.take(std::max<size_t>(m_self.size() * sizeof(BlockRef), 16));
+    sp.eig_self.nblocks = (int)m_self.size();
+    if (img && !m_self.empty()) img->put(sp.eig_self.map_off, m_self.data(), m_self.size() * sizeof(BlockRef));
     sp.eig_desc_off = sp.eig_tick.desc_off;
     sp.eig_norm = sp.eig_tick;
     sp.eig_norm.map_off = da.take(std::max<size_t>(m_norm.size() * sizeof(BlockRef), 16));
@@ -709,9 +725,20 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     int tick = 0;
     int gs = 0;
     for (; gs < p->max_global_sweeps && !all_done; ++gs) {
-      for (int t = 0; t < sp.gsteps; ++t, ++tick)
-        launch_jacobi_tick(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
-                           p->inner_sweeps, sp.tick_lds, sp.super, s);
+      for (int t = 0; t < sp.gsteps; ++t, ++tick) {
+        if (sp.mode == 2) {
+          bool any_first = false;     // does any problem start a sweep of its own at this tick?
+          for (int q = 0; q < sp.neig && !any_first; ++q) any_first = (tick % (sp.nb[q] - 1)) == 0;
+          if (any_first)
+            launch_jacobi_self(ed, (const BlockRef*)D(sp.eig_self.map_off), sp.eig_self.nblocks, tick, p->tol,
+                               p->inner_sweeps, sp.ld_max, s);
+          launch_jacobi_cross(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
+                              sp.ld_max, s);
+        } else {
+          launch_jacobi_tick(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
+                             p->inner_sweeps, sp.tick_lds, sp.mode == 1, s);
+        }
+      }
       HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipStreamSynchronize(s));
@@ -757,6 +784,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
   HIP_OK(h, hipGetLastError());
   for (int i = 0; i < 8; ++i) p->last_ms[i] = acc_ms[i];
   p->last_sweeps = total_sweeps;
+  if (p->debug) { (void)hipStreamSynchronize(s); dump_stamps(); }
   return TADMM_OK;
 }
 
@@ -852,7 +880,7 @@ static void gram_geom(int m, int n, StepGeom& st) {
   st.N = std::min(m, n);
   st.Npad = (int)align_up(st.N, 4 * kJB);
   st.nb = st.Npad / kJB;
-  st.ld = (int)align_up(st.N, 32);
+  st.ld = (int)align_up(st.N, st.N <= jacobi_cross_max_ld() ? 128 : 32);
   st.nt = (st.N + 31) / 32;
   const int64_t K = st.trans ? m : n;
   const int ntp = st.nt * (st.nt + 1) / 2;
@@ -914,7 +942,7 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
 }
 
 size_t tadmm_eigh_scratch_bytes(int N) {
-  const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, 32);
+  const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, N <= jacobi_cross_max_ld() ? 128 : 32);
   return align_up(Npad * ld * 8, 256) + align_up(sizeof(EigDesc), 256) + 4 * align_up(Npad * sizeof(BlockRef), 256) +
          align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024;
 }
@@ -924,10 +952,14 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   if (!h || !G || !evals_out || !evecs_out || !scratch || N <= 0) return TADMM_ERR_INVALID;
   if (scratch_bytes < tadmm_eigh_scratch_bytes(N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "eigh scratch too small");
   hipStream_t s = (hipStream_t)stream_;
-  const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, 32), nb = Npad / kJB;
-  const bool super = jacobi_tick2_fits(ld) && !getenv("TADMM_NO_SUPER");
+  const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, N <= jacobi_cross_max_ld() ? 128 : 32),
+            nb = Npad / kJB;
+  int mode = getenv("TADMM_JACOBI_MODE") ? atoi(getenv("TADMM_JACOBI_MODE")) : 1;
+  if (mode == 2 && (ld > jacobi_cross_max_ld() || ld % 128)) mode = 1;
+  if (mode == 1 && !jacobi_tick2_fits(ld)) mode = 0;
+  const bool super = mode >= 1;
   const int units = super ? nb / 2 : nb;
-  const size_t tick_lds = super ? jacobi_tick2_lds_bytes(ld) : jacobi_tick_lds_bytes(ld);
+  const size_t tick_lds = mode == 1 ? jacobi_tick2_lds_bytes(ld) : jacobi_tick_lds_bytes(ld);
   char* base = (char*)scratch;
   size_t off = 0;
   double* XT = (double*)(base + off); off += align_up((size_t)Npad * ld * 8, 256);
@@ -935,7 +967,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   BlockRef* m_tick = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
   BlockRef* m_norm = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
   BlockRef* m_ext = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
-  off += align_up(Npad * sizeof(BlockRef), 256);
+  BlockRef* m_self = (BlockRef*)(base + off); off += align_up(Npad * sizeof(BlockRef), 256);
   double* lam = (double*)(base + off); off += align_up((size_t)Npad * 8, 256);
   double* sigma = (double*)(base + off); off += align_up((size_t)Npad * 8, 256);
   int32_t* order = (int32_t*)(base + off); off += align_up((size_t)Npad * 4, 256);
@@ -955,6 +987,9 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   HIP_OK(h, hipMemcpyAsync(m_tick, vt.data(), vt.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipMemcpyAsync(m_norm, vn.data(), vn.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipMemcpyAsync(m_ext, ve.data(), ve.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  std::vector<BlockRef> vs2;
+  for (int b = 0; b < nb / 2; ++b) vs2.push_back(BlockRef{0, b});
+  HIP_OK(h, hipMemcpyAsync(m_self, vs2.data(), vs2.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipStreamSynchronize(s));
   launch_jacobi_init(edev, 1, s);
   const double tol = 1e-9;
@@ -963,8 +998,14 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   double hoff[3];
   int hdone = 0;
   for (; gs < 40 && !conv; ++gs) {
-    for (int t = 0; t < units - 1; ++t, ++tick)
-      launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 1, tick_lds, super, s);
+    for (int t = 0; t < units - 1; ++t, ++tick) {
+      if (mode == 2) {
+        if (t == 0) launch_jacobi_self(edev, m_self, units, tick, tol, 1, ld, s);
+        launch_jacobi_cross(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
+      } else {
+        launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 1, tick_lds, mode == 1, s);
+      }
+    }
     HIP_OK(h, hipMemcpyAsync(hoff, offs, 24, hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipMemcpyAsync(&hdone, done, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipStreamSynchronize(s));

@@ -1,0 +1,40 @@
+"""Condense rocprofv3 output (kernel stats + FETCH_SIZE / WRITE_SIZE passes) into a markdown summary."""
+import csv, glob, os, sys, collections, json
+
+out = sys.argv[1]
+
+def find(pat):
+    r = glob.glob(os.path.join(out, pat), recursive=True)
+    return r[0] if r else None
+
+print("# rocprofv3 summary:", os.path.basename(out))
+b = os.path.join(out, "bench_under_trace.json")
+if os.path.exists(b):
+    try:
+        d = json.loads(open(b).read().strip().splitlines()[-1])
+        print("\nbench under trace: %.2f ms/step, phases %s" % (d["ms_per_step"], {k: round(v, 3) for k, v in d.get("phases_ms", {}).items()}))
+    except Exception as e:
+        print("bench json unreadable:", e)
+st = find("trace/**/*kernel_stats.csv")
+if st:
+    print("\n## kernel stats (--kernel-trace --stats)\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for row in csv.DictReader(open(st)):
+        name = row["Name"].split("(")[0].replace("tadmm::", "")
+        if len(name) > 60: name = name[:57] + "..."
+        print("| %s | %s | %.3f | %.2f | %s |" % (name, row["Calls"], float(row["TotalDurationNs"]) / 1e6, float(row["AverageNs"]) / 1e3, row["Percentage"]))
+for tag, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
+    f = find(pat)
+    if not f:
+        print("\n(no %s pass found)" % tag); continue
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(f)):
+        if row.get("Counter_Name") != tag: continue
+        name = row["Kernel_Name"].split("(")[0].replace("tadmm::", "")
+        a = acc[name]; a[0] += 1; a[1] += float(row["Counter_Value"])
+    print("\n## %s per launch (raw counter, KiB; FETCH_SIZE under-reports wide streaming reads by 2x on gfx950)\n" % tag)
+    print("| kernel | launches | avg per launch (KiB) | total (MiB) |")
+    print("|---|---|---|---|")
+    for name, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:12]:
+        print("| %s | %d | %.1f | %.1f |" % (name[:60], n, tot / n, tot / 1024))
