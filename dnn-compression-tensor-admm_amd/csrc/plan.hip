@@ -135,7 +135,7 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     st.nt = (st.N + 31) / 32;
     const int64_t K = st.trans ? st.m : st.cols;
     const int ntp = st.nt * (st.nt + 1) / 2;
-    int ks = (1024 + ntp - 1) / ntp;
+    int ks = (256 + ntp - 1) / ntp;   // ~256 workgroups per problem; levels batch 15-30 problems
     const int maxks = (int)std::max<int64_t>(1, (K + 255) / 256);
     ks = std::max(1, std::min(ks, maxks));
     st.kchunk = (int)align_up((K + ks - 1) / ks, 64);
@@ -884,7 +884,7 @@ static void gram_geom(int m, int n, StepGeom& st) {
   st.nt = (st.N + 31) / 32;
   const int64_t K = st.trans ? m : n;
   const int ntp = st.nt * (st.nt + 1) / 2;
-  int ks = (1024 + ntp - 1) / ntp;
+  int ks = (256 + ntp - 1) / ntp;   // ~256 workgroups per problem; levels batch 15-30 problems
   const int maxks = (int)std::max<int64_t>(1, (K + 255) / 256);
   ks = std::max(1, std::min(ks, maxks));
   st.kchunk = (int)align_up((K + ks - 1) / ks, 64);
