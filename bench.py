@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--config", default="resnet50_tt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: time every part of an N-way layer shard one after the other on this GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,19 +99,44 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % ndev)          # one rank per GPU (rehearsals may fold ranks onto one card)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("TADMM_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from tadmm import ops, sched, workloads
     model, hp, fmt = workloads.build(args.config, seed=0)
     entries, names = layer_entries(model, hp, fmt, dev)
     flops = [sched.layer_flops(e["kind"], list(e["W"].shape), e.get("tt_shapes"), e["ranks"]) for e in entries]
     costs = [f["svd"] + f["rec"] for f in flops]
+    if args.emulate_world > 1:
+        emu = sched.lpt_partition(costs, args.emulate_world)
+        res = []
+        for part in emu:
+            for i in part:
+                entries[i]["U"] = torch.zeros_like(entries[i]["W"])
+                entries[i]["Z"] = torch.empty_like(entries[i]["W"])
+            pl = ops.ProjectionPlan([entries[i] for i in part])
+            for _ in range(2):
+                pl.run(update_u=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pl.run(update_u=True)
+            torch.cuda.synchronize()
+            res.append(dict(layers=len(part), ms=1e3 * (time.perf_counter() - t0) / args.steps,
+                            gflop=sum(costs[i] for i in part) / 1e9, names=[names[i] for i in part][:4]))
+            pl.close()
+        print(json.dumps({"emulate_world": args.emulate_world, "max_ms": max(r["ms"] for r in res), "parts": res}))
+        return
     parts = sched.lpt_partition(costs, world)
     mine = parts[rank]
     for i in mine:

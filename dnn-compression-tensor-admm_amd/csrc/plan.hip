@@ -158,6 +158,7 @@ struct StepPlan {
   int neig = 0;
   int gsteps = 0;                 // ticks per global sweep = max(nb-1)
   size_t tick_lds = 0;            // dynamic LDS of the tick launches of this step
+  int last_sweeps = 0;            // global sweeps the previous run needed (polls start 2 sweeps before that)
   bool super = false;             // LDS-resident super-pair kernel (all problems of the level fit)
   int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 2: register/LDS cross kernel + self
   Phase eig_self;                 // mode 2: block map of the once-per-sweep self kernel (nb/2 workgroups per problem)
@@ -739,6 +740,9 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
                              p->inner_sweeps, sp.tick_lds, sp.mode == 1, s);
         }
       }
+      // Convergence poll (one small D2H + stream sync).  Jacobi needs about the same number of sweeps
+      // from one ADMM iteration to the next, so sweeps that cannot be the last one are not polled.
+      if (gs + 3 < sp.last_sweeps) continue;
       HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipStreamSynchronize(s));
@@ -754,6 +758,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
         if (!conv) { all_done = false; break; }
       }
     }
+    sp.last_sweeps = gs;
     total_sweeps += gs;
     if (p->debug) {
       (void)hipStreamSynchronize(s);
