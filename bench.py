@@ -204,10 +204,22 @@ def main():
         my_mfma32 = sum(flops[i]["proj"] + flops[i]["rec"] for i in mine)
         my_bytes = 16.0 * sum(flops[i]["numel"] for i in mine)
         gram_tf = my_gram / (ph["gram_ms"] * 1e-3) / 1e12 if ph["gram_ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+               # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); bench.py cannot run rocprofv3 itself
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if args.config == "resnet50_tt" and world == 1:
+                traffic = pm["kernels"]["gram_partial_kernel"]["hbm_bytes_per_launch_corrected"]
+                traffic_src = "profiles/r01_pmc_traffic.json (per launch of gram_partial_kernel)"
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "gram_partial_kernel+gram_reduce_kernel (fp64 MFMA 16x16x4)",
                            "achieved": gram_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": gram_tf / PEAK_F64_MFMA_TFLOPS, "traffic": None,
-                           "note": "algorithmic 2*M*N^2 per unfolding / measured phase time on rank 0"}
+                           "frac": gram_tf / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                           "launches_per_step": 4,
+                           "note": "dominant MATRIX-CORE kernel; algorithmic 2*M*N^2 per unfolding (18.63 GFLOP/step) / "
+                                   "HIP-event time of the Gram launches on rank 0.  The dominant kernel by TIME is the "
+                                   "latency-bound Jacobi tick (see phases_ms / roofline_other.eig_time_share)."}
         gemm_ms = ph["project_ms"] + ph["reconstruct_ms"]
         sweep_ms = ph["unfold_ms"] + ph["fold_update_ms"]
         out["phases_ms"] = ph
