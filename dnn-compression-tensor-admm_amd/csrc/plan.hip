@@ -159,6 +159,7 @@ struct StepPlan {
   int gsteps = 0;                 // ticks per global sweep = max(nb-1)
   size_t tick_lds = 0;            // dynamic LDS of the tick launches of this step
   int last_sweeps = 0;            // global sweeps the previous run needed (polls start 2 sweeps before that)
+  std::vector<double> prev_off;   // per problem: observed off-diagonal of its previous own sweep
   bool super = false;             // LDS-resident super-pair kernel (all problems of the level fit)
   int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 2: register/LDS cross kernel + self
   Phase eig_self;                 // mode 2: block map of the once-per-sweep self kernel (nb/2 workgroups per problem)
@@ -722,6 +723,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     tic(0);
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
     launch_jacobi_init(ed, sp.neig, s);
+    sp.prev_off.assign(sp.neig, 0.0);
     bool all_done = false;
     int tick = 0;
     int gs = 0;
@@ -747,15 +749,34 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
       HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipStreamSynchronize(s));
       all_done = true;
+      if (p->debug) {
+        double mxo = 0; int nd = 0;
+        for (int q = 0; q < sp.neig; ++q) {
+          if (p->h_done[q]) { ++nd; continue; }
+          const int steps = sp.nb[q] - 1;
+          if (tick % steps == 0) mxo = std::max(mxo, p->h_off[3 * q + ((tick / steps - 1) & 1)]);
+        }
+        fprintf(stderr, "[tadmm]   sweep %d: max observed off %.3e, done %d/%d\n", gs, mxo, nd, sp.neig);
+      }
       for (int q = 0; q < sp.neig; ++q) {
         if (p->h_done[q]) continue;
         const int steps = sp.nb[q] - 1;
         bool conv = false;
         if (tick % steps == 0) {   // this problem just finished its own sweep number tick/steps - 1
           const int swp = tick / steps - 1;
-          conv = p->h_off[3 * q + (swp & 1)] < p->tol;
+          const double m = p->h_off[3 * q + (swp & 1)];       // largest off-diagonal the sweep saw BEFORE rotating
+          conv = m < p->tol;
+          // Quadratic phase: the sweep that observed m leaves about C*m^2 behind, C estimated from the last
+          // two sweeps (x10 safety).  Stop when that prediction is below the target instead of spending one
+          // more sweep just to observe it.
+          const double mp = sp.prev_off[q];
+          if (!conv && mp > 0.0 && mp < 1e-1 && m < 1e-3) {
+            const double C = 10.0 * std::max(1.0, m / (mp * mp));
+            conv = C * m * m < 10.0 * p->tol;      // post-sweep target 1e-8: eigenvector errors stay << 1e-5
+          }
+          sp.prev_off[q] = m;
         }
-        if (!conv) { all_done = false; break; }
+        if (!conv) all_done = false;
       }
     }
     sp.last_sweeps = gs;
