@@ -174,6 +174,32 @@ class ADMM:
         if epoch > int(0.85 * epochs):                                          # admm.py:87-89
             self.rho = factor * self.init_rho
 
+    # ------------------------------------------------------------------ checkpointing (beyond the reference)
+    def state_dict(self):
+        """ADMM state for checkpoint/resume.  The reference never saves Z, U or rho (engines.py:333-347), so a
+        resumed --admm run silently restarts from U=0, Z=proj(W) (engines.py:241-245); this closes that gap."""
+        return {"rho": self.rho, "init_rho": self.init_rho, "format": self.format,
+                "z": {k: v.detach().cpu() for k, v in self.z.items()},
+                "u": {k: v.detach().cpu() for k, v in self.u.items()},
+                "ranks": {k: (list(v) if not isinstance(v, int) else v) for k, v in self.hp_dict.ranks.items()},
+                "logger": {k: list(v) for k, v in self.logger.items()} if self.log else None}
+
+    def load_state_dict(self, state):
+        if state["format"] != self.format:
+            raise ValueError(f"checkpoint format {state['format']!r} != {self.format!r}")
+        if set(state["z"]) != set(self.z):
+            raise KeyError("checkpoint layers differ from the rank table")
+        self.rho, self.init_rho = state["rho"], state["init_rho"]
+        for k in self.z:                       # in place: the projection plan holds these pointers
+            self.z[k].copy_(state["z"][k])
+            self.u[k].copy_(state["u"][k])
+        for k, r in state["ranks"].items():    # re-apply clamps recorded at save time
+            tbl = self.hp_dict.ranks.get(k)
+            if isinstance(tbl, list):
+                tbl[:] = r
+        if self.log and state.get("logger"):
+            self.logger = {k: list(v) for k, v in state["logger"].items()}
+
     # ------------------------------------------------------------------ fused penalty
     def _penalty_forward(self, params):
         import ctypes as C
