@@ -133,6 +133,9 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     // row length of the eigen-solver's X image: 1 KiB chunks for the register-resident cross kernel
     st.ld = (int)align_up(st.N, st.N <= jacobi_cross_max_ld() ? 128 : 32);
     st.nt = (st.N + 31) / 32;
+    if (!st.skip && jacobi_tick_lds_bytes(st.ld) > 160 * 1024)
+      CTX_FAIL(h, TADMM_ERR_UNSUPPORTED,
+               "TT step %d: eigen-problem of size %d exceeds the LDS-resident Jacobi kernels (max ~1270)", s, st.N);
     const int64_t K = st.trans ? st.m : st.cols;
     const int ntp = st.nt * (st.nt + 1) / 2;
     int ks = (256 + ntp - 1) / ntp;   // ~256 workgroups per problem; levels batch 15-30 problems
