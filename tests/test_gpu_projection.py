@@ -217,3 +217,69 @@ def test_projection_properties_resnet50(dev):
     r = hp.ranks[k][1]
     assert sv[r] <= 1e-5 * sv[0], (sv[r], sv[0])
     assert sv[r - 1] >= 1e-2 * sv[0]
+
+
+def test_ragged_shapes_and_edge_ranks_vs_oracle(dev):
+    """Odd, unaligned and degenerate shapes (scalar fall-back paths of every kernel), rank 1, rank >= min dim
+    (clamp), against the oracle."""
+    from tadmm import ops
+    from tadmm._cabi import KIND_SVD, KIND_TT_CONV, KIND_TT_LINEAR
+    rng = np.random.default_rng(11)
+    cases = [
+        (KIND_TT_CONV, (5, 3, 3, 3), [5, 9, 3], [1, 3, 2, 1]),
+        (KIND_TT_CONV, (6, 10, 1, 1), [6, 1, 10], [1, 4, 4, 1]),
+        (KIND_TT_CONV, (9, 7, 5, 5), [3, 3, 25, 7], [1, 2, 5, 3, 1]),
+        (KIND_TT_CONV, (4, 4, 3, 3), [4, 9, 4], [1, 9, 9, 1]),            # ranks above every unfolding -> clamp, identity
+        (KIND_TT_LINEAR, (7, 5), [7, 5], [1, 2, 1]),
+        (KIND_TT_LINEAR, (30, 77), [2, 3, 5, 7, 11], [1, 2, 4, 6, 3, 1]),
+        (KIND_TT_LINEAR, (1, 13), [1, 13], [1, 1, 1]),
+        (KIND_SVD, (11, 3), None, 1),
+        (KIND_SVD, (3, 17, 1, 1), None, [5]),                              # rank > min dim
+        (KIND_SVD, (33, 65), None, 7),
+    ]
+    layers, refs = [], []
+    for kind, shape, tts, ranks in cases:
+        w = rng.standard_normal(shape).astype(np.float32)
+        u = (0.3 * rng.standard_normal(shape)).astype(np.float32)
+        zin = w + u
+        if kind == KIND_TT_CONV:
+            r = list(ranks)
+            z = O.prune_conv_rank_tt(zin, tts, r)
+        elif kind == KIND_TT_LINEAR:
+            r = list(ranks)
+            O.ten2tt(np.zeros(tts, np.float32), tts, r)
+            z = O.prune_linear_rank_tt(zin, tts, list(ranks))
+        else:
+            r = None
+            z = O.prune_conv_rank_svd(zin, ranks) if len(shape) == 4 else O.prune_linear_rank_svd(zin, ranks)
+        refs.append((w, u, np.asarray(z, dtype=np.float32).reshape(shape), r))
+        L = dict(kind=kind, W=torch.from_numpy(w).to(dev), U=torch.from_numpy(u).to(dev),
+                 Z=torch.empty(shape, device=dev), ranks=ranks)
+        if tts is not None:
+            L["tt_shapes"] = tts
+        layers.append(L)
+    plan = ops.ProjectionPlan(layers)
+    resid = plan.run(update_u=True).cpu().numpy()
+    for i, (L, (w, u, z, r)) in enumerate(zip(layers, refs)):
+        got = L["Z"].cpu().numpy()
+        scale = max(1e-6, np.abs(w + u).max())
+        np.testing.assert_allclose(got, z, rtol=0, atol=2e-5 * scale, err_msg=str(cases[i]))
+        np.testing.assert_allclose(L["U"].cpu().numpy(), u + (w - got), atol=1e-6)
+        assert abs(resid[i] - float(((w - got).astype(np.float64) ** 2).sum())) <= 1e-5 * max(1.0, resid[i])
+        if r is not None:
+            assert plan.ranks[i] == r, cases[i]                                      # bit-exact clamp
+
+
+def test_empty_table_is_a_noop(dev):
+    from tadmm.admm import ADMM
+
+    class HPe:
+        ranks = {"not.there": [1, 2, 1]}
+        tt_shapes = {"not.there": [2, 2]}
+
+    m = torch.nn.Linear(4, 4).to(dev)
+    a = ADMM(m, 1e-3, HPe, "tt", dev)
+    a.update()
+    assert a.z == {} and a.u == {}
+    loss = torch.ones((), device=dev)
+    assert a.append_admm_loss(loss) is loss
