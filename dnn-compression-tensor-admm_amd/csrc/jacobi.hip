@@ -122,23 +122,26 @@ __device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lan
                                                    bool within, int inner_sweeps) {
   double (*Hs)[kHP] = S.H;
   double (*Qs)[kHP] = S.Q;
-  const double floor2 = hmax * 1e-28;                 // lambda < 1e-14 lambda_max: padding / exact zeros
-  const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;   // keeps the fp32 angle estimate in range
-  const double wscale = 1e-14 / tol;
-  double mx = 0.0;
+  const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;   // keeps the fp32 estimates in range
+  // The measure only gates convergence (it is compared with tol with orders of magnitude of margin), so it is
+  // evaluated in fp32 fast math on entries scaled by 1/hmax: r_i = h_ii/hmax lies in (1e-28, 1].
+  const float wscale = (float)(1e-14 / tol);
+  float mxf = 0.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int e = lane * 4 + k;
     const int i = e >> 4, j = e & 15;
     if (i < j) {
-      const double hii = Hs[i][i], hjj = Hs[j][j];
-      const double hmin = fmin(hii, hjj);
-      if (hmin > floor2) {
-        const double w = fmax(1.0, wscale * sqrt(hmax / hmin));   // lambda_max / lambda_min of the pair
-        mx = fmax(mx, fabs(Hs[i][j]) * rsqrt(hii * hjj) / w);
+      const float ri = (float)(Hs[i][i] * inv_hmax), rj = (float)(Hs[j][j] * inv_hmax);
+      const float rmin = fminf(ri, rj);
+      if (rmin > 1e-28f) {                                  // lambda < 1e-14 lambda_max: padding / exact zeros
+        const float hij = fabsf((float)(Hs[i][j] * inv_hmax));
+        const float w = fmaxf(1.0f, wscale * __builtin_amdgcn_rsqf(rmin));        // lambda_max / lambda_min
+        mxf = fmaxf(mxf, hij * __builtin_amdgcn_rsqf(ri) * __builtin_amdgcn_rsqf(rj) * __builtin_amdgcn_rcpf(w));
       }
     }
   }
+  double mx = (double)mxf;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
   mx = __shfl(mx, 0, 64);
