@@ -38,7 +38,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kPair = 2 * kJB;  // 16
-constexpr int kHP = kPair + 1;  // padded leading dimension of the 16x16 LDS images
+constexpr int kHP = kPair + 2;  // padded leading dimension of the 16x16 LDS images (even: 16-byte aligned rows)
 
 __global__ __launch_bounds__(256) void jacobi_init_kernel(const EigDesc* __restrict__ descs) {
   const EigDesc d = descs[blockIdx.x];
@@ -219,6 +219,120 @@ __device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lan
   return mx;
 }
 
+// ---- DPP helpers (row = 16 lanes) ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over each aligned group of 8 lanes, result in all 8 (xor 1, xor 2, then mirror inside the group)
+__device__ __forceinline__ double group8_sum(double v) {
+  v += dpp_mov_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141>(v);   // row_half_mirror
+  return v;
+}
+
+// Inner solve, row formulation: two-sided cyclic Jacobi on the 16x16 symmetric H, carried as the pair
+//   Y = Q^T H0   (rows rotated only)      and      Qt = Q^T,
+// so that the current two-sided matrix is H_cur = Y Qt^T and its entries are 16-term dot products
+//   h_pp = <Y_p,Qt_p>,  h_qq = <Y_q,Qt_q>,  h_pq = <Y_p,Qt_q>.
+// A rotation then only mixes ROWS p,q of Y and of Qt.  8 lanes per index pair, 2 entries per lane and row;
+// the three dot products are reduced on the DPP crossbar inside the 8-lane group, so every lane derives (c, s)
+// itself: no coefficient broadcast, no partner table, one LDS round trip per step.  Exactly the rotations of
+// two-sided Jacobi on H (same accuracy for small eigen-components), at less than half the latency of the
+// element-wise formulation `pair_inner_solve`.
+// Q is accumulated TRANSPOSED in S.Q during the pass (row p = column p of Q) and transposed back at the end.
+__device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, int lane, double hmax, double tol,
+                                                        bool within) {
+  double (*Hs)[kHP] = S.H;
+  double (*Qs)[kHP] = S.Q;
+  const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;
+  const float wscale = (float)(1e-14 / tol);
+  float mxf = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = lane * 4 + k;
+    const int i = e >> 4, j = e & 15;
+    if (i < j) {
+      const float ri = (float)(Hs[i][i] * inv_hmax), rj = (float)(Hs[j][j] * inv_hmax);
+      const float rmin = fminf(ri, rj);
+      if (rmin > 1e-28f) {
+        const float hij = fabsf((float)(Hs[i][j] * inv_hmax));
+        const float w = fmaxf(1.0f, wscale * __builtin_amdgcn_rsqf(rmin));
+        mxf = fmaxf(mxf, hij * __builtin_amdgcn_rsqf(ri) * __builtin_amdgcn_rsqf(rj) * __builtin_amdgcn_rcpf(w));
+      }
+    }
+  }
+  double mx = (double)mxf;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  mx = __shfl(mx, 0, 64);
+  int did = 0;
+  if (mx > 1e-15) {
+    const int g8 = lane >> 3, l8 = lane & 7;
+    const double scale2 = inv_hmax;                       // entries of H_cur are ~lambda^2 <= hmax
+    const int nsteps = within ? (kJB + kJB - 1) : kJB;
+    for (int st = 0; st < nsteps; ++st) {
+      int p, q;
+      if (st < kJB) { p = g8; q = kJB + ((g8 + st) & (kJB - 1)); }
+      else {
+        int a2, b2;
+        rr_pair(kJB, st - kJB, g8 & 3, a2, b2);
+        const int base = (g8 >> 2) * kJB;
+        p = base + min(a2, b2); q = base + max(a2, b2);
+      }
+      double2_t* yp = reinterpret_cast<double2_t*>(&Hs[p][2 * l8]);
+      double2_t* yq = reinterpret_cast<double2_t*>(&Hs[q][2 * l8]);
+      double2_t* tp = reinterpret_cast<double2_t*>(&Qs[p][2 * l8]);
+      double2_t* tq = reinterpret_cast<double2_t*>(&Qs[q][2 * l8]);
+      const double2_t vp = *yp, vq = *yq, up = *tp, uq = *tq;
+      // entries of the current two-sided matrix H_cur = Q^T H0 Q = Y * (Q^T)^T :  h_ab = <Y_a, Qt_b>
+      const double a = group8_sum(vp.x * up.x + vp.y * up.y);
+      const double b = group8_sum(vq.x * uq.x + vq.y * uq.y);
+      const double g = group8_sum(vp.x * uq.x + vp.y * uq.y);
+      if (g * g > 1e-36 * fabs(a * b) && fabs(g) > 1e-300) {   // uniform inside the 8-lane group
+        const float zf = (float)((b - a) * scale2), wf = (float)(2.0 * g * scale2);
+        const float az = fabsf(zf), aw = fabsf(wf);
+        float tf;
+        if (az >= aw) {
+          const float u = wf * __builtin_amdgcn_rcpf(az);
+          tf = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + u * u));
+        } else {
+          const float v = az * __builtin_amdgcn_rcpf(aw);
+          tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
+        }
+        if (zf < 0.0f) tf = -tf;
+        const double t = (double)tf;
+        const double x = 1.0 + t * t;
+        double c = __builtin_amdgcn_rsq(x);
+        c = c * (1.5 - 0.5 * x * c * c);
+        c = c * (1.5 - 0.5 * x * c * c);
+        const double s = t * c;
+        // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
+        *yp = double2_t{c * vp.x - s * vq.x, c * vp.y - s * vq.y};
+        *yq = double2_t{s * vp.x + c * vq.x, s * vp.y + c * vq.y};
+        *tp = double2_t{c * up.x - s * uq.x, c * up.y - s * uq.y};
+        *tq = double2_t{s * up.x + c * uq.x, s * up.y + c * uq.y};
+        did = 1;
+      }
+      wave_lds_fence();
+    }
+    did = __any(did);
+    // S.Q holds Q^T: transpose in place (read everything, fence, write)
+    double qt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; qt[k] = Qs[e & 15][e >> 4]; }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; Qs[e >> 4][e & 15] = qt[k]; }
+    wave_lds_fence();
+  }
+  if (lane == 0) *S.rotated = did;
+  return mx;
+}
+
 // Dynamic LDS layout of tick1 (doubles): X[16][ldp] | PairScratch
 __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restrict__ descs,
                                                           const BlockRef* __restrict__ map, int tick, double tol,
@@ -275,7 +389,9 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   pair_gram_reduce(S, tid);
   __syncthreads();
   if (wave == 0) {
-    const double mx = pair_inner_solve(S, lane, d.off[2], tol, step == 0, inner_sweeps);
+    const bool fast = (inner_sweeps == 1);
+    const double mx = fast ? pair_inner_solve_fast(S, lane, d.off[2], tol, step == 0)
+                           : pair_inner_solve(S, lane, d.off[2], tol, step == 0, inner_sweeps & 15);
     if (lane == 0)
       atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mx));
   }
@@ -369,6 +485,7 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
   if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
 
   const double hmax = d.off[2];
+  const bool fast = (inner_sweeps == 1);     // row formulation of the inner solve (default)
   const int per = ld >> 2;
   double mxall = 0.0;
   int any_rot = 0;
@@ -388,7 +505,8 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
     __syncthreads();
     STAMP(2 + 4 * round);
     if (wv == 0) {
-      const double mx = pair_inner_solve(S, lane, hmax, tol, round == 0, inner_sweeps);
+      const double mx = fast ? pair_inner_solve_fast(S, lane, hmax, tol, round == 0)
+                             : pair_inner_solve(S, lane, hmax, tol, round == 0, inner_sweeps & 15);
       mxall = fmax(mxall, mx);
     }
     __syncthreads();
