@@ -67,6 +67,7 @@ struct EigDesc {
   float* out_a;       // mode0: Uf (N x r) ; mode1: Vs (N x r)
   float* out_b;       // mode1: Tnext (r x N) ; mode0: unused
   double* evec_out;   // optional: [r][N] eigenvectors as rows in fp64 (tadmm_eigh_f64), nullable
+  double* sblk;       // [Npad/16][16*16] carried self-Gram of every 16-column super-block (tick3), nullable
 };
 void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s);
 size_t jacobi_tick_lds_bytes(int ld_max);    // dynamic LDS of a tick1 launch whose largest problem has row length ld_max
@@ -77,6 +78,12 @@ bool jacobi_tick2_fits(int ld_max);
 void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, size_t lds_bytes, bool super, hipStream_t s);
 void dump_stamps();
+size_t jacobi_tick3_lds_bytes(int ld_max);
+bool jacobi_tick3_fits(int ld_max);
+// tick3: super-pair kernel with carried self-Grams (one cross-Gram per launch, round-2 solve overlapped with the
+// round-1 update).  Needs launch_jacobi_self on the first tick of every sweep (it refreshes EigDesc::sblk).
+void launch_jacobi_tick3(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
+                         int ld_max, hipStream_t s);
 // register/LDS-resident cross phase (jacobi_cross.hip) + its once-per-sweep companion (tick1 in self mode)
 size_t jacobi_cross_lds_bytes(int ld_max);
 int jacobi_cross_max_ld();

@@ -245,7 +245,7 @@ __device__ __forceinline__ double group8_sum(double v) {
 // element-wise formulation `pair_inner_solve`.
 // Q is accumulated TRANSPOSED in S.Q during the pass (row p = column p of Q) and transposed back at the end.
 __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, int lane, double hmax, double tol,
-                                                        bool within) {
+                                                        bool within, double* __restrict__ hcur_out = nullptr) {
   double (*Hs)[kHP] = S.H;
   double (*Qs)[kHP] = S.Q;
   const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;
@@ -320,6 +320,17 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       wave_lds_fence();
     }
     did = __any(did);
+    if (hcur_out) {     // Gram of the rotated columns: H_cur[a][b] = <Y_a, Qt_b>  (16-term dot products)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane * 4 + k;
+        const int a = e >> 4, b = e & 15;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < kPair; ++t) acc += Hs[a][t] * Qs[b][t];
+        hcur_out[e] = acc;
+      }
+    }
     // S.Q holds Q^T: transpose in place (read everything, fence, write)
     double qt[4];
 #pragma unroll
@@ -328,6 +339,9 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; Qs[e >> 4][e & 15] = qt[k]; }
     wave_lds_fence();
+  } else if (hcur_out) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; hcur_out[e] = Hs[e >> 4][e & 15]; }
   }
   if (lane == 0) *S.rotated = did;
   return mx;
@@ -390,8 +404,9 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   __syncthreads();
   if (wave == 0) {
     const bool fast = (inner_sweeps == 1);
-    const double mx = fast ? pair_inner_solve_fast(S, lane, d.off[2], tol, step == 0)
-                           : pair_inner_solve(S, lane, d.off[2], tol, step == 0, inner_sweeps & 15);
+    double* hcur = (self_mode && d.sblk) ? d.sblk + (int64_t)br.local * (kPair * kPair) : nullptr;
+    const double mx = (fast || hcur) ? pair_inner_solve_fast(S, lane, d.off[2], tol, step == 0, hcur)
+                                     : pair_inner_solve(S, lane, d.off[2], tol, step == 0, inner_sweeps & 15);
     if (lane == 0)
       atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mx));
   }
@@ -555,11 +570,255 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
   STAMP(20);
 }
 
+// ------------------------------------------------------------------------------------------------
+// tick3: super-pair kernel with carried self-Grams.
+//
+// Every 16-column super-block b carries its 16x16 self-Gram S_b = X_b^T X_b in global memory (EigDesc::sblk,
+// refreshed exactly once per sweep by the self kernel).  A launch on the super-pair (A, B) then needs only the
+// CROSS Gram C = X_A^T X_B -- one 16x16 MFMA tile accumulated over all rows (128 MFMAs instead of the 512 of
+// four sub-pair Grams) -- to assemble the full 32x32 Gram  H32 = [S_A C; C^T S_B]  in LDS.  Both rounds of
+// sub-pair solves work on 16x16 sub-blocks of H32; between the rounds H32 is transformed by the round-1
+// rotations (H32 <- Q1^T H32 Q1, small LDS arithmetic), so the round-2 solves do NOT need the updated columns:
+// they run on waves 0 and 4 WHILE the other six waves apply Q1 to the 32 columns on the matrix cores.
+// Critical path per launch: load -> cross Gram -> solve 1 -> solve 2 (|| apply 1) -> apply 2 -> store.
+//
+// Dynamic LDS (doubles): X[32][ldp] | R[2048] (cross-Gram partials, then H32[32][34]) |
+//                        per half: H[16][18] Q1[16][18] Q2[16][18] | flags
+// ------------------------------------------------------------------------------------------------
+constexpr int kH32 = kSuper + 2;    // leading dimension of the 32x32 LDS image
+
+__device__ __forceinline__ int sub_index(int u, int v, int k) { return (k < kJB) ? (u * kJB + k) : (v * kJB + (k - kJB)); }
+
+// X[:, sub-pair (u,v)] <- X[:, (u,v)] * Q  for the tiles it = wi, wi+nw, ...   (rows of the transposed slab)
+__device__ __forceinline__ void apply_q_tiles(double* __restrict__ Xs, int ldp, int ld, const double (*Q)[kHP], int u,
+                                              int v, int wi, int nw, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  double qa[4];
+  int rowk[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    qa[t] = Q[4 * t + q][r];                                  // A operand: A[m=a][k=b] = Q[b][a]
+    rowk[t] = sub_index(u, v, 4 * t + q) * ldp;               // k = 4t+q (B operand row) and D row q+4e share this map
+  }
+  const int ntile = ld >> 4;
+  for (int it = wi; it < ntile; it += nw) {
+    const int col = it * 16 + r;
+    double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], Xs[rowk[t] + col], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Xs[rowk[e] + col] = acc[e];   // in place: a tile is touched by one wave only
+  }
+}
+
+// H32 <- Q^T H32 Q with Q = the two 16x16 rotations Qa (on index set of sub-pair (ua,va)) and Qb (on (ub,vb)).
+// 512 threads; two passes through registers, in place.
+// H32 <- Q^T H32 Q with Q = the two 16x16 rotations Qa (on the index set of sub-pair (ua,va)) and Qb (on (ub,vb)).
+// In the permuted coordinates [idx_a | idx_b] Q is block diagonal, so each of the two products is four
+// independent 16x16x16 tile products: waves 0-3 take one tile each (4 MFMAs), operands straight from LDS.
+template <int ua, int va, int ub, int vb>
+__device__ __forceinline__ void transform_h32(double (*H32)[kH32], const double (*Qa)[kHP], const double (*Qb)[kHP],
+                                              int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int I = (wave >> 1) & 1, J = wave & 1;                     // tile (I,J) for waves 0..3
+  const double (*QI)[kHP] = I ? Qb : Qa;
+  const double (*QJ)[kHP] = J ? Qb : Qa;
+  auto idx = [](int blk, int k) { return blk ? sub_index(ub, vb, k) : sub_index(ua, va, k); };
+  double4_t acc = {0, 0, 0, 0};
+  if (wave < 4) {   // T = H32 * Q :  T[I][J] = H32[I][J] * Q_J
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(H32[idx(I, r)][idx(J, 4 * t + kq)], QJ[4 * t + kq][r], acc, 0, 0, 0);
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) H32[idx(I, kq + 4 * e)][idx(J, r)] = acc[e];
+  }
+  __syncthreads();
+  acc = double4_t{0, 0, 0, 0};
+  if (wave < 4) {   // H32' = Q^T * T :  H32'[I][J] = Q_I^T * T[I][J]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(QI[4 * t + kq][r], H32[idx(I, 4 * t + kq)][idx(J, r)], acc, 0, 0, 0);
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) H32[idx(I, kq + 4 * e)][idx(J, r)] = acc[e];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __restrict__ descs,
+                                                           const BlockRef* __restrict__ map, int tick, double tol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const BlockRef br = map[blockIdx.x];
+  const EigDesc d = descs[br.prob];
+  if (*d.done) return;
+  const int nbs = d.nb >> 1;
+  const int steps = nbs - 1;
+  const int sweep = tick / steps;
+  const int step = tick - sweep * steps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = wave >> 2, wv = wave & 3, th = tid & 255;
+  if (step == 0 && sweep > 0) {
+    if (d.off[(sweep - 1) & 1] < tol) {
+      if (br.local == 0 && tid == 0) *d.done = 1;
+      return;
+    }
+  }
+  const int ld = d.ld, ldp = ld + 2;
+#ifdef TADMM_STAMPS
+  const unsigned long long t0 = clock64();
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) g_stamps[31] += 1;
+#endif
+  double* Xs = smem;
+  double* R = Xs + kSuper * ldp;                                   // 2048 doubles
+  double (*H32)[kH32] = reinterpret_cast<double (*)[kH32]>(R);     // aliases R after the reduction
+  double* hb = R + 2048 + half * (3 * kPair * kHP);
+  double (*Hs)[kHP] = reinterpret_cast<double (*)[kHP]>(hb);
+  double (*Q1)[kHP] = Hs + kPair;
+  double (*Q2)[kHP] = Q1 + kPair;
+  double (*Q1o)[kHP] = reinterpret_cast<double (*)[kHP]>(R + 2048 + (1 - half) * (3 * kPair * kHP)) + kPair;
+  double (*Q2o)[kHP] = Q1o + kPair;
+  int* flags = reinterpret_cast<int*>(R + 2048 + 2 * (3 * kPair * kHP));   // [0..1] rotated round 1, [2..3] round 2
+
+  int sa, sb;
+  rr_pair(nbs, step, br.local, sa, sb);
+  const int r = lane & 15, q = lane >> 4;
+  double* __restrict__ XT = d.XT;
+
+  // ---- load the 32 columns; fetch the two carried self-Grams into registers ----
+  const double sreg = d.sblk[(int64_t)(tid < 256 ? sa : sb) * (kPair * kPair) + th];
+  {
+    const int c2n = ld >> 1;
+    const int total = kSuper * c2n;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += 512) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
+      const double2_t v = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
+      *reinterpret_cast<double2_t*>(Xs + row * ldp + 2 * c2) = v;
+    }
+  }
+  __syncthreads();
+  STAMP(0);
+  if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
+
+  // ---- cross Gram C = X_A^T X_B : every wave reduces ld/8 rows ----
+  {
+    const int per = ld >> 3;                                       // ld % 128 == 0 -> per % 16 == 0
+    const double* ra = Xs + r * ldp + 2 * q;
+    const double* rb = Xs + (kPair + r) * ldp + 2 * q;
+    double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    for (int i = wave * per; i < (wave + 1) * per; i += 8) {
+      const double2_t va = *reinterpret_cast<const double2_t*>(ra + i);
+      const double2_t vb = *reinterpret_cast<const double2_t*>(rb + i);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va.x, vb.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(va.y, vb.y, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) R[wave * 256 + lane * 4 + e] = acc0[e] + acc1[e];
+  }
+  __syncthreads();
+  double cval = 0.0;
+  if (tid < 256) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) cval += R[w * 256 + tid];
+  }
+  __syncthreads();                                                  // R is dead from here: H32 takes its place
+  if (tid < 256) {
+    const int l = tid >> 2, reg = tid & 3;
+    const int hr = (l >> 4) + 4 * reg, hc = l & 15;                 // D layout: C[a = hr][b = hc]
+    H32[hr][kPair + hc] = cval;
+    H32[kPair + hc][hr] = cval;
+    H32[th >> 4][th & 15] = sreg;                                   // S_A
+  } else {
+    H32[kPair + (th >> 4)][kPair + (th & 15)] = sreg;               // S_B
+  }
+  __syncthreads();
+  STAMP(1);
+
+  const double hmax = d.off[2];
+  double mxall = 0.0;
+  // ---- round 1: (0,2) | (1,3) ----
+  {
+    const int u = half ? 1 : 0, v = half ? 3 : 2;
+    Hs[th >> 4][th & 15] = H32[sub_index(u, v, th >> 4)][sub_index(u, v, th & 15)];
+    Q1[th >> 4][th & 15] = ((th >> 4) == (th & 15)) ? 1.0 : 0.0;
+    __syncthreads();
+    if (wv == half) {      // waves 0 and 5: different SIMDs (waves 0 and 4 would share one)
+      PairScratch S;
+      S.H = Hs; S.Q = Q1; S.rotated = flags + half;
+      mxall = fmax(mxall, pair_inner_solve_fast(S, lane, hmax, tol, false));
+    }
+    __syncthreads();
+  }
+  STAMP(2);
+  // ---- H32 <- Q1^T H32 Q1 ; extract round 2: (0,3) | (1,2) ----
+  {
+    double (*Qa)[kHP] = half ? Q1o : Q1;       // rotation of sub-pair (0,2)
+    double (*Qb)[kHP] = half ? Q1 : Q1o;       // rotation of sub-pair (1,3)
+    transform_h32<0, 2, 1, 3>(H32, Qa, Qb, tid);
+    const int u = half ? 1 : 0, v = half ? 2 : 3;
+    Hs[th >> 4][th & 15] = H32[sub_index(u, v, th >> 4)][sub_index(u, v, th & 15)];
+    Q2[th >> 4][th & 15] = ((th >> 4) == (th & 15)) ? 1.0 : 0.0;
+    __syncthreads();
+  }
+  STAMP(3);
+  // ---- round-2 solves on waves 0 and 4, round-1 column update on the other six waves ----
+  if (wv == half) {
+    PairScratch S;
+    S.H = Hs; S.Q = Q2; S.rotated = flags + 2 + half;
+    __builtin_amdgcn_s_setprio(3);        // the solve is the critical path; the updater waves have slack
+    mxall = fmax(mxall, pair_inner_solve_fast(S, lane, hmax, tol, false));
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    const int u = half ? 1 : 0, v = half ? 3 : 2;                   // this half's round-1 sub-pair
+    const int wi = (wv > half) ? wv - 1 : wv;                       // 0..2 among the three non-solver waves
+    if (flags[half]) apply_q_tiles(Xs, ldp, ld, Q1, u, v, wi, 3, lane);
+  }
+  __syncthreads();
+  STAMP(4);
+  // ---- round-2 column update (all waves), final self-Grams ----
+  {
+    const int u = half ? 1 : 0, v = half ? 2 : 3;
+    if (flags[2 + half]) apply_q_tiles(Xs, ldp, ld, Q2, u, v, wv, 4, lane);
+    double (*Qa)[kHP] = half ? Q2o : Q2;       // (0,3)
+    double (*Qb)[kHP] = half ? Q2 : Q2o;       // (1,2)
+    transform_h32<0, 3, 1, 2>(H32, Qa, Qb, tid);
+  }
+  STAMP(5);
+  if (wv == half && lane == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mxall));
+  const int any_rot = flags[0] | flags[1] | flags[2] | flags[3];
+  if (!any_rot) return;
+  // ---- store columns and self-Grams ----
+  d.sblk[(int64_t)(tid < 256 ? sa : sb) * (kPair * kPair) + th] =
+      (tid < 256) ? H32[th >> 4][th & 15] : H32[kPair + (th >> 4)][kPair + (th & 15)];
+  {
+    const int c2n = ld >> 1;
+    const int total = kSuper * c2n;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += 512) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
+      *reinterpret_cast<double2_t*>(XT + (int64_t)grow * ld + 2 * c2) =
+          *reinterpret_cast<const double2_t*>(Xs + row * ldp + 2 * c2);
+    }
+  }
+  STAMP(20);
+}
+
 #ifdef TADMM_STAMPS
 void dump_stamps() {
   unsigned long long h[32];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return;
   const double n = h[31] ? (double)h[31] : 1.0;
+  fprintf(stderr, "[stamps3] launches=%llu cumulative: load=%.0f gram=%.0f solve1=%.0f xform=%.0f solve2||apply1=%.0f apply2+xform=%.0f end=%.0f\n",
+          h[31], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[20] / n);
   fprintf(stderr, "[stamps] launches=%llu  cumulative cycles/launch: load=%.0f", h[31], h[0] / n);
   for (int r = 0; r < 3; ++r)
     fprintf(stderr, " | r%d gram=%.0f red=%.0f inner=%.0f upd=%.0f", r, h[1 + 4 * r] / n, h[2 + 4 * r] / n, h[3 + 4 * r] / n, h[4 + 4 * r] / n);
@@ -650,6 +909,27 @@ void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s) {
 }
 
 size_t jacobi_tick_lds_bytes(int ld_max) { return ((size_t)kPair * (ld_max + 2) + kPairScratchDoubles) * 8; }
+size_t jacobi_tick3_lds_bytes(int ld_max) {
+  return ((size_t)kSuper * (ld_max + 2) + 2048 + 2 * (3 * kPair * kHP)) * 8 + 16;
+}
+bool jacobi_tick3_fits(int ld_max) { return jacobi_tick3_lds_bytes(ld_max) <= 160 * 1024; }
+void launch_jacobi_tick3(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
+                         int ld_max, hipStream_t s) {
+  if (nblocks <= 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(jacobi_tick3_kernel, dim3(nblocks), dim3(512), jacobi_tick3_lds_bytes(ld_max), s, descs_dev, map_dev,
+                     tick, tol);
+  const hipError_t e = hipPeekAtLastError();
+  if (e != hipSuccess)
+    fprintf(stderr, "[tadmm] jacobi tick3 launch failed: %s (blocks=%d lds=%zu)\n", hipGetErrorString(e), nblocks,
+            jacobi_tick3_lds_bytes(ld_max));
+}
 size_t jacobi_tick2_lds_bytes(int ld_max) { return ((size_t)kSuper * (ld_max + 2) + 2 * kPairScratchDoubles) * 8; }
 bool jacobi_tick2_fits(int ld_max) { return jacobi_tick2_lds_bytes(ld_max) <= 160 * 1024; }
 

@@ -413,6 +413,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       const size_t lam_off = ar.take((size_t)st.Npad * 8);
       const size_t ord_off = ar.take((size_t)st.Npad * 4);
       const size_t sig_off = ar.take((size_t)st.r * 8);
+      const size_t sblk_off = ar.take((size_t)(st.Npad / 16) * 256 * 8);
       P->sigma_off[l][s] = sig_off;
       e.lam = (double*)dev(lam_off);
       e.order = (int32_t*)dev(ord_off);
@@ -422,6 +423,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       e.out_a = st.trans ? (float*)dev(vs[l]) : core_dev;
       e.out_b = st.trans ? tnext : nullptr;
       e.evec_out = nullptr;
+      e.sblk = (double*)dev(sblk_off);
       ed.push_back(e);
       sp.nb.push_back(st.nb);
       sp.ld_max = std::max(sp.ld_max, st.ld);
@@ -469,7 +471,8 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     // tick shape of the level: LDS-resident super-pairs when every problem fits, else plain pairs
     {
       const char* em = getenv("TADMM_JACOBI_MODE");
-      int want = em ? atoi(em) : 1;
+      int want = em ? atoi(em) : 3;
+      if (want == 3 && (!jacobi_tick3_fits(sp.ld_max) || sp.ld_max % 64)) want = 1;
       if (want == 2 && (sp.ld_max > jacobi_cross_max_ld() || sp.ld_max % 128)) want = 1;
       if (want == 1 && !jacobi_tick2_fits(sp.ld_max)) want = 0;
       sp.mode = sp.neig > 0 ? want : 0;
@@ -483,7 +486,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       sp.nb[pq] = units;
       sp.gsteps = std::max(sp.gsteps, units - 1);
       for (int b = 0; b < units / 2; ++b) m_tick.push_back(BlockRef{pq, b});
-      if (sp.mode == 2) for (int b = 0; b < units; ++b) m_self.push_back(BlockRef{pq, b});
+      if (sp.mode >= 2) for (int b = 0; b < units; ++b) m_self.push_back(BlockRef{pq, b});
     }
     place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m_tick);
     sp.eig_self = sp.eig_tick;
@@ -732,14 +735,18 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     int gs = 0;
     for (; gs < p->max_global_sweeps && !all_done; ++gs) {
       for (int t = 0; t < sp.gsteps; ++t, ++tick) {
-        if (sp.mode == 2) {
+        if (sp.mode >= 2) {
           bool any_first = false;     // does any problem start a sweep of its own at this tick?
           for (int q = 0; q < sp.neig && !any_first; ++q) any_first = (tick % (sp.nb[q] - 1)) == 0;
           if (any_first)
             launch_jacobi_self(ed, (const BlockRef*)D(sp.eig_self.map_off), sp.eig_self.nblocks, tick, p->tol,
                                p->inner_sweeps, sp.ld_max, s);
-          launch_jacobi_cross(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
-                              sp.ld_max, s);
+          if (sp.mode == 3)
+            launch_jacobi_tick3(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
+                                sp.ld_max, s);
+          else
+            launch_jacobi_cross(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
+                                sp.ld_max, s);
         } else {
           launch_jacobi_tick(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
                              p->inner_sweeps, sp.tick_lds, sp.mode == 1, s);
@@ -973,7 +980,7 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
 size_t tadmm_eigh_scratch_bytes(int N) {
   const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, N <= jacobi_cross_max_ld() ? 128 : 32);
   return align_up(Npad * ld * 8, 256) + align_up(sizeof(EigDesc), 256) + 4 * align_up(Npad * sizeof(BlockRef), 256) +
-         align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024;
+         align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024 + align_up((Npad / 16) * 256 * 8, 256);
 }
 
 int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, double* evecs_out, void* scratch,
@@ -983,7 +990,8 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   hipStream_t s = (hipStream_t)stream_;
   const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, N <= jacobi_cross_max_ld() ? 128 : 32),
             nb = Npad / kJB;
-  int mode = getenv("TADMM_JACOBI_MODE") ? atoi(getenv("TADMM_JACOBI_MODE")) : 1;
+  int mode = getenv("TADMM_JACOBI_MODE") ? atoi(getenv("TADMM_JACOBI_MODE")) : 3;
+  if (mode == 3 && (!jacobi_tick3_fits(ld) || ld % 64)) mode = 1;
   if (mode == 2 && (ld > jacobi_cross_max_ld() || ld % 128)) mode = 1;
   if (mode == 1 && !jacobi_tick2_fits(ld)) mode = 0;
   const bool super = mode >= 1;
@@ -1001,13 +1009,15 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   double* sigma = (double*)(base + off); off += align_up((size_t)Npad * 8, 256);
   int32_t* order = (int32_t*)(base + off); off += align_up((size_t)Npad * 4, 256);
   double* offs = (double*)(base + off); off += 64;
-  int32_t* done = (int32_t*)(base + off);
+  int32_t* done = (int32_t*)(base + off); off += 64;
+  double* sblk = (double*)(base + off);
   HIP_OK(h, hipMemsetAsync(XT, 0, (size_t)Npad * ld * 8, s));
   HIP_OK(h, hipMemcpy2DAsync(XT, (size_t)ld * 8, G, (size_t)N * 8, (size_t)N * 8, N, hipMemcpyDeviceToDevice, s));
   EigDesc e;
   memset(&e, 0, sizeof e);
   e.XT = XT; e.N = N; e.Npad = Npad; e.ld = ld; e.nb = nb; e.off = offs; e.done = done; e.lam = lam; e.order = order;
   e.sigma = sigma; e.r = N; e.mode = 2; e.out_a = nullptr; e.out_b = nullptr; e.evec_out = evecs_out;
+  e.sblk = sblk;
   std::vector<BlockRef> vt, vn, ve;
   for (int b = 0; b < units / 2; ++b) vt.push_back(BlockRef{0, b});
   for (int b = 0; b < (Npad + 3) / 4; ++b) vn.push_back(BlockRef{0, b});
@@ -1028,9 +1038,10 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   int hdone = 0;
   for (; gs < 40 && !conv; ++gs) {
     for (int t = 0; t < units - 1; ++t, ++tick) {
-      if (mode == 2) {
+      if (mode >= 2) {
         if (t == 0) launch_jacobi_self(edev, m_self, units, tick, tol, 1, ld, s);
-        launch_jacobi_cross(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
+        if (mode == 3) launch_jacobi_tick3(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
+        else launch_jacobi_cross(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
       } else {
         launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 1, tick_lds, mode == 1, s);
       }
