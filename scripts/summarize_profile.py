@@ -38,3 +38,23 @@ for tag, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE
     print("|---|---|---|---|")
     for name, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:12]:
         print("| %s | %d | %.1f | %.1f |" % (name[:60], n, tot / n, tot / 1024))
+
+# machine-readable per-launch HBM traffic (bench.py reads profiles/r01_pmc_traffic.json for roofline.traffic)
+ff, fw = find("pmc_fetch/**/*counter_collection.csv"), find("pmc_write/**/*counter_collection.csv")
+if ff and fw:
+    per = collections.defaultdict(dict)
+    for tag, f in (("FETCH_SIZE", ff), ("WRITE_SIZE", fw)):
+        acc = collections.defaultdict(lambda: [0, 0.0])
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != tag: continue
+            name = row["Kernel_Name"].split("(")[0].replace("tadmm::", "")
+            a = acc[name]; a[0] += 1; a[1] += float(row["Counter_Value"])
+        for name, (n, tot) in acc.items():
+            per[name][tag + "_KiB_per_launch_raw"] = tot / n
+            per[name]["launches"] = n
+    for name, d in per.items():
+        d["hbm_bytes_per_launch_corrected"] = (2 * d.get("FETCH_SIZE_KiB_per_launch_raw", 0.0) + d.get("WRITE_SIZE_KiB_per_launch_raw", 0.0)) * 1024
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1, ResNet-50 TT",
+               "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (FETCH_SIZE counts 64 B per 128-B request on gfx950)",
+               "kernels": {k: v for k, v in per.items() if not k.startswith("void at::") and not k.startswith("__amd")}},
+              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
