@@ -273,44 +273,73 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
   if (mx > 1e-15) {
     const int g8 = lane >> 3, l8 = lane & 7;
     const double scale2 = inv_hmax;                       // entries of H_cur are ~lambda^2 <= hmax
-    const int nsteps = within ? (kJB + kJB - 1) : kJB;
-    for (int st = 0; st < nsteps; ++st) {
-      int p, q;
-      if (st < kJB) { p = g8; q = kJB + ((g8 + st) & (kJB - 1)); }
-      else {
-        int a2, b2;
-        rr_pair(kJB, st - kJB, g8 & 3, a2, b2);
-        const int base = (g8 >> 2) * kJB;
-        p = base + min(a2, b2); q = base + max(a2, b2);
+    // rotation of rows (p,q) given the three entries a = h_pp, b = h_qq, g = h_pq of the current matrix
+    auto rotation = [&](double a, double b, double g, double& c, double& s) -> bool {
+      if (!(g * g > 1e-36 * fabs(a * b) && fabs(g) > 1e-300)) return false;   // uniform inside the 8-lane group
+      const float zf = (float)((b - a) * scale2), wf = (float)(2.0 * g * scale2);
+      const float az = fabsf(zf), aw = fabsf(wf);
+      float tf;
+      if (az >= aw) {
+        const float u = wf * __builtin_amdgcn_rcpf(az);
+        tf = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + u * u));
+      } else {
+        const float v = az * __builtin_amdgcn_rcpf(aw);
+        tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
       }
+      if (zf < 0.0f) tf = -tf;
+      const double t = (double)tf;
+      const double x = 1.0 + t * t;
+      c = __builtin_amdgcn_rsq(x);
+      c = c * (1.5 - 0.5 * x * c * c);
+      c = c * (1.5 - 0.5 * x * c * c);
+      s = t * c;
+      return true;
+    };
+    // cross pairs: row p = g8 stays with this 8-lane group for all kJB steps -> carried in registers; only the
+    // q rows (which move from group to group) make the LDS round trip
+    {
+      const int p = g8;
+      double2_t* yp = reinterpret_cast<double2_t*>(&Hs[p][2 * l8]);
+      double2_t* tp = reinterpret_cast<double2_t*>(&Qs[p][2 * l8]);
+      double2_t vp = *yp, up = *tp;
+      for (int st = 0; st < kJB; ++st) {
+        const int q = kJB + ((g8 + st) & (kJB - 1));
+        double2_t* yq = reinterpret_cast<double2_t*>(&Hs[q][2 * l8]);
+        double2_t* tq = reinterpret_cast<double2_t*>(&Qs[q][2 * l8]);
+        const double2_t vq = *yq, uq = *tq;
+        const double a = group8_sum(vp.x * up.x + vp.y * up.y);
+        const double b = group8_sum(vq.x * uq.x + vq.y * uq.y);
+        const double g = group8_sum(vp.x * uq.x + vp.y * uq.y);
+        double c, s;
+        if (rotation(a, b, g, c, s)) {
+          // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
+          *yq = double2_t{s * vp.x + c * vq.x, s * vp.y + c * vq.y};
+          *tq = double2_t{s * up.x + c * uq.x, s * up.y + c * uq.y};
+          vp = double2_t{c * vp.x - s * vq.x, c * vp.y - s * vq.y};
+          up = double2_t{c * up.x - s * uq.x, c * up.y - s * uq.y};
+          did = 1;
+        }
+        wave_lds_fence();
+      }
+      *yp = vp; *tp = up;
+      wave_lds_fence();
+    }
+    // within-block pairs (self pass only)
+    for (int st = 0; within && st < kJB - 1; ++st) {
+      int a2, b2;
+      rr_pair(kJB, st, g8 & 3, a2, b2);
+      const int base = (g8 >> 2) * kJB;
+      const int p = base + min(a2, b2), q = base + max(a2, b2);
       double2_t* yp = reinterpret_cast<double2_t*>(&Hs[p][2 * l8]);
       double2_t* yq = reinterpret_cast<double2_t*>(&Hs[q][2 * l8]);
       double2_t* tp = reinterpret_cast<double2_t*>(&Qs[p][2 * l8]);
       double2_t* tq = reinterpret_cast<double2_t*>(&Qs[q][2 * l8]);
       const double2_t vp = *yp, vq = *yq, up = *tp, uq = *tq;
-      // entries of the current two-sided matrix H_cur = Q^T H0 Q = Y * (Q^T)^T :  h_ab = <Y_a, Qt_b>
       const double a = group8_sum(vp.x * up.x + vp.y * up.y);
       const double b = group8_sum(vq.x * uq.x + vq.y * uq.y);
       const double g = group8_sum(vp.x * uq.x + vp.y * uq.y);
-      if (g * g > 1e-36 * fabs(a * b) && fabs(g) > 1e-300) {   // uniform inside the 8-lane group
-        const float zf = (float)((b - a) * scale2), wf = (float)(2.0 * g * scale2);
-        const float az = fabsf(zf), aw = fabsf(wf);
-        float tf;
-        if (az >= aw) {
-          const float u = wf * __builtin_amdgcn_rcpf(az);
-          tf = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + u * u));
-        } else {
-          const float v = az * __builtin_amdgcn_rcpf(aw);
-          tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
-        }
-        if (zf < 0.0f) tf = -tf;
-        const double t = (double)tf;
-        const double x = 1.0 + t * t;
-        double c = __builtin_amdgcn_rsq(x);
-        c = c * (1.5 - 0.5 * x * c * c);
-        c = c * (1.5 - 0.5 * x * c * c);
-        const double s = t * c;
-        // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
+      double c, s;
+      if (rotation(a, b, g, c, s)) {
         *yp = double2_t{c * vp.x - s * vq.x, c * vp.y - s * vq.y};
         *yq = double2_t{s * vp.x + c * vq.x, s * vp.y + c * vq.y};
         *tp = double2_t{c * up.x - s * uq.x, c * up.y - s * uq.y};

@@ -150,6 +150,21 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH "Workgroup
+// dispatch").  Re-order a block map so that CONSECUTIVE logical blocks land on the same XCD: the tournament
+// hands a super-block from workgroup q to q+-1 between launches, so the next launch finds it in that XCD's L2.
+static void xcd_group(std::vector<BlockRef>& m) {
+  const char* e = getenv("TADMM_XCD_MAP");   // default on; 0 = plain order (for A/B measurements)
+  if (e && !atoi(e)) return;
+  const int G = (int)m.size();
+  if (G < 16) return;
+  std::vector<BlockRef> out(G);
+  int i = 0;
+  for (int x = 0; x < 8; ++x)
+    for (int b = x; b < G; b += 8) out[b] = m[i++];
+  m.swap(out);
+}
+
 struct Phase {  // one grouped launch: descriptor array + block map inside the device arena
   size_t desc_off = 0, map_off = 0;
   int nprob = 0, nblocks = 0;
@@ -488,8 +503,10 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       for (int b = 0; b < units / 2; ++b) m_tick.push_back(BlockRef{pq, b});
       if (sp.mode >= 2) for (int b = 0; b < units; ++b) m_self.push_back(BlockRef{pq, b});
     }
+    xcd_group(m_tick);
     place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m_tick);
     sp.eig_self = sp.eig_tick;
+    xcd_group(m_self);
     sp.eig_self.map_off = da.take(std::max<size_t>(m_self.size() * sizeof(BlockRef), 16));
     sp.eig_self.nblocks = (int)m_self.size();
     if (img && !m_self.empty()) img->put(sp.eig_self.map_off, m_self.data(), m_self.size() * sizeof(BlockRef));
