@@ -222,8 +222,9 @@ __device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lan
 // ---- DPP helpers (row = 16 lanes) ----
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  // every lane has a valid source for the controls used here, so the "old" operand is left undefined (mov_dpp)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 // sum over each aligned group of 8 lanes, result in all 8 (xor 1, xor 2, then mirror inside the group)
@@ -232,6 +233,22 @@ __device__ __forceinline__ double group8_sum(double v) {
   v += dpp_mov_f64<0x4E>(v);    // quad_perm [2,3,0,1]
   v += dpp_mov_f64<0x141>(v);   // row_half_mirror
   return v;
+}
+
+// max over the 64 lanes of a wave, result in every lane: DPP inside the 16-lane rows, readlane across them
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxf(v, dpp_mov_f32<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov_f32<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov_f32<0x141>(v));   // row_half_mirror
+  v = fmaxf(v, dpp_mov_f32<0x140>(v));   // row_mirror
+  const int b = __float_as_int(v);
+  const float m0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), m1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float m2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), m3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
 // Inner solve, row formulation: two-sided cyclic Jacobi on the 16x16 symmetric H, carried as the pair
@@ -244,6 +261,8 @@ __device__ __forceinline__ double group8_sum(double v) {
 // two-sided Jacobi on H (same accuracy for small eigen-components), at less than half the latency of the
 // element-wise formulation `pair_inner_solve`.
 // Q is accumulated TRANSPOSED in S.Q during the pass (row p = column p of Q) and transposed back at the end.
+// kKeepQt: leave Q^T in S.Q (the caller's MFMA operand reads take the transposed index order for free).
+template <bool kKeepQt = false>
 __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, int lane, double hmax, double tol,
                                                         bool within, double* __restrict__ hcur_out = nullptr) {
   double (*Hs)[kHP] = S.H;
@@ -265,10 +284,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       }
     }
   }
-  double mx = (double)mxf;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
-  mx = __shfl(mx, 0, 64);
+  const double mx = (double)wave_max_f32(mxf);
   int did = 0;
   if (mx > 1e-15) {
     const int g8 = lane >> 3, l8 = lane & 7;
@@ -289,8 +305,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       if (zf < 0.0f) tf = -tf;
       const double t = (double)tf;
       const double x = 1.0 + t * t;
-      c = __builtin_amdgcn_rsq(x);
-      c = c * (1.5 - 0.5 * x * c * c);
+      c = __builtin_amdgcn_rsq(x);            // ~2^-26 relative; one Newton step squares that
       c = c * (1.5 - 0.5 * x * c * c);
       s = t * c;
       return true;
@@ -360,14 +375,15 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
         hcur_out[e] = acc;
       }
     }
-    // S.Q holds Q^T: transpose in place (read everything, fence, write)
-    double qt[4];
+    if (!kKeepQt) {   // S.Q holds Q^T: transpose in place (read everything, fence, write)
+      double qt[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; qt[k] = Qs[e & 15][e >> 4]; }
-    wave_lds_fence();
+      for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; qt[k] = Qs[e & 15][e >> 4]; }
+      wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; Qs[e >> 4][e & 15] = qt[k]; }
-    wave_lds_fence();
+      for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; Qs[e >> 4][e & 15] = qt[k]; }
+      wave_lds_fence();
+    }
   } else if (hcur_out) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; hcur_out[e] = Hs[e >> 4][e & 15]; }
@@ -618,6 +634,7 @@ constexpr int kH32 = kSuper + 2;    // leading dimension of the 32x32 LDS image
 
 __device__ __forceinline__ int sub_index(int u, int v, int k) { return (k < kJB) ? (u * kJB + k) : (v * kJB + (k - kJB)); }
 
+// (Q is passed TRANSPOSED, as the inner solve leaves it.)
 // X[:, sub-pair (u,v)] <- X[:, (u,v)] * Q  for the tiles it = wi, wi+nw, ...   (rows of the transposed slab)
 __device__ __forceinline__ void apply_q_tiles(double* __restrict__ Xs, int ldp, int ld, const double (*Q)[kHP], int u,
                                               int v, int wi, int nw, int lane) {
@@ -626,7 +643,7 @@ __device__ __forceinline__ void apply_q_tiles(double* __restrict__ Xs, int ldp, 
   int rowk[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    qa[t] = Q[4 * t + q][r];                                  // A operand: A[m=a][k=b] = Q[b][a]
+    qa[t] = Q[r][4 * t + q];                                  // A operand: A[m=a][k=b] = Q[b][a] = Qt[a][b]
     rowk[t] = sub_index(u, v, 4 * t + q) * ldp;               // k = 4t+q (B operand row) and D row q+4e share this map
   }
   const int ntile = ld >> 4;
@@ -640,11 +657,37 @@ __device__ __forceinline__ void apply_q_tiles(double* __restrict__ Xs, int ldp, 
   }
 }
 
-// H32 <- Q^T H32 Q with Q = the two 16x16 rotations Qa (on index set of sub-pair (ua,va)) and Qb (on (ub,vb)).
-// 512 threads; two passes through registers, in place.
+// Same product, result written to the global column image (XT[j][:] = column j) instead of LDS: 16 lanes write
+// 128 contiguous bytes of one column.
+__device__ __forceinline__ void apply_q_tiles_store(const double* __restrict__ Xs, int ldp, int ld, const double (*Q)[kHP],
+                                                    int u, int v, int wi, int nw, int lane, double* __restrict__ XT, int sa,
+                                                    int sb) {
+  const int r = lane & 15, q = lane >> 4;
+  double qa[4];
+  int rowk[4];
+  int64_t growk[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    qa[t] = Q[r][4 * t + q];
+    const int row = sub_index(u, v, 4 * t + q);
+    rowk[t] = row * ldp;
+    growk[t] = (int64_t)((row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair))) * ld;
+  }
+  const int ntile = ld >> 4;
+  for (int it = wi; it < ntile; it += nw) {
+    const int col = it * 16 + r;
+    double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], Xs[rowk[t] + col], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) XT[growk[e] + col] = acc[e];
+  }
+}
+
 // H32 <- Q^T H32 Q with Q = the two 16x16 rotations Qa (on the index set of sub-pair (ua,va)) and Qb (on (ub,vb)).
 // In the permuted coordinates [idx_a | idx_b] Q is block diagonal, so each of the two products is four
 // independent 16x16x16 tile products: waves 0-3 take one tile each (4 MFMAs), operands straight from LDS.
+// Qa / Qb are passed TRANSPOSED (Qt[a][b] = Q[b][a]).
 template <int ua, int va, int ub, int vb>
 __device__ __forceinline__ void transform_h32(double (*H32)[kH32], const double (*Qa)[kHP], const double (*Qb)[kHP],
                                               int tid) {
@@ -654,28 +697,21 @@ __device__ __forceinline__ void transform_h32(double (*H32)[kH32], const double 
   const double (*QI)[kHP] = I ? Qb : Qa;
   const double (*QJ)[kHP] = J ? Qb : Qa;
   auto idx = [](int blk, int k) { return blk ? sub_index(ub, vb, k) : sub_index(ua, va, k); };
-  double4_t acc = {0, 0, 0, 0};
-  if (wave < 4) {   // T = H32 * Q :  T[I][J] = H32[I][J] * Q_J
+  double4_t acc = {0, 0, 0, 0}, out = {0, 0, 0, 0};
+  if (wave < 4) {
+    // T = H32[I][J] * Q_J, then H32'[I][J] = Q_I^T * T.  The D layout of the first product (lane (r,kq) holds
+    // T[kq+4e][r] in register e) IS the B-operand layout of the second (k-step t wants T[4t+kq][r]): e = t, so
+    // the chained product needs no LDS round trip.
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(H32[idx(I, r)][idx(J, 4 * t + kq)], QJ[4 * t + kq][r], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(H32[idx(I, r)][idx(J, 4 * t + kq)], QJ[r][4 * t + kq], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out = __builtin_amdgcn_mfma_f64_16x16x4f64(QI[r][4 * t + kq], acc[t], out, 0, 0, 0);
   }
-  __syncthreads();
+  __syncthreads();                   // every tile has been read before any is overwritten
   if (wave < 4) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) H32[idx(I, kq + 4 * e)][idx(J, r)] = acc[e];
-  }
-  __syncthreads();
-  acc = double4_t{0, 0, 0, 0};
-  if (wave < 4) {   // H32' = Q^T * T :  H32'[I][J] = Q_I^T * T[I][J]
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(QI[4 * t + kq][r], H32[idx(I, 4 * t + kq)][idx(J, r)], acc, 0, 0, 0);
-  }
-  __syncthreads();
-  if (wave < 4) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) H32[idx(I, kq + 4 * e)][idx(J, r)] = acc[e];
+    for (int e = 0; e < 4; ++e) H32[idx(I, kq + 4 * e)][idx(J, r)] = out[e];
   }
   __syncthreads();
 }
@@ -781,7 +817,7 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
     if (wv == half) {      // waves 0 and 5: different SIMDs (waves 0 and 4 would share one)
       PairScratch S;
       S.H = Hs; S.Q = Q1; S.rotated = flags + half;
-      mxall = fmax(mxall, pair_inner_solve_fast(S, lane, hmax, tol, false));
+      mxall = fmax(mxall, pair_inner_solve_fast<true>(S, lane, hmax, tol, false));
     }
     __syncthreads();
   }
@@ -802,7 +838,7 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
     PairScratch S;
     S.H = Hs; S.Q = Q2; S.rotated = flags + 2 + half;
     __builtin_amdgcn_s_setprio(3);        // the solve is the critical path; the updater waves have slack
-    mxall = fmax(mxall, pair_inner_solve_fast(S, lane, hmax, tol, false));
+    mxall = fmax(mxall, pair_inner_solve_fast<true>(S, lane, hmax, tol, false));
     __builtin_amdgcn_s_setprio(0);
   } else {
     const int u = half ? 1 : 0, v = half ? 3 : 2;                   // this half's round-1 sub-pair
@@ -811,32 +847,24 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   }
   __syncthreads();
   STAMP(4);
-  // ---- round-2 column update (all waves), final self-Grams ----
+  // ---- final self-Grams, then the round-2 column update straight from the MFMA accumulators to HBM ----
+  if (wv == half && lane == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mxall));
+  const int any_rot = flags[0] | flags[1] | flags[2] | flags[3];
+  if (!any_rot) return;
   {
-    const int u = half ? 1 : 0, v = half ? 2 : 3;
-    if (flags[2 + half]) apply_q_tiles(Xs, ldp, ld, Q2, u, v, wv, 4, lane);
     double (*Qa)[kHP] = half ? Q2o : Q2;       // (0,3)
     double (*Qb)[kHP] = half ? Q2 : Q2o;       // (1,2)
     transform_h32<0, 3, 1, 2>(H32, Qa, Qb, tid);
   }
   STAMP(5);
-  if (wv == half && lane == 0)
-    atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mxall));
-  const int any_rot = flags[0] | flags[1] | flags[2] | flags[3];
-  if (!any_rot) return;
-  // ---- store columns and self-Grams ----
   d.sblk[(int64_t)(tid < 256 ? sa : sb) * (kPair * kPair) + th] =
       (tid < 256) ? H32[th >> 4][th & 15] : H32[kPair + (th >> 4)][kPair + (th & 15)];
   {
-    const int c2n = ld >> 1;
-    const int total = kSuper * c2n;
-#pragma unroll 4
-    for (int idx = tid; idx < total; idx += 512) {
-      const int row = idx / c2n, c2 = idx - row * c2n;
-      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
-      *reinterpret_cast<double2_t*>(XT + (int64_t)grow * ld + 2 * c2) =
-          *reinterpret_cast<const double2_t*>(Xs + row * ldp + 2 * c2);
-    }
+    // the two halves' round-2 sub-pairs (0,3) and (1,2) cover all 32 columns; a sub-pair that was not rotated
+    // in round 2 has Q2 = I and the product is an exact copy of what round 1 left in LDS
+    const int u = half ? 1 : 0, v = half ? 2 : 3;
+    apply_q_tiles_store(Xs, ldp, ld, Q2, u, v, wv, 4, lane, XT, sa, sb);
   }
   STAMP(20);
 }
