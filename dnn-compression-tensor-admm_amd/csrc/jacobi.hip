@@ -251,6 +251,12 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
+#ifdef TADMM_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define SSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { const unsigned long long tn = clock64(); g_stamps[i] += tn - ts; ts = tn; } } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
 // Inner solve, row formulation: two-sided cyclic Jacobi on the 16x16 symmetric H, carried as the pair
 //   Y = Q^T H0   (rows rotated only)      and      Qt = Q^T,
 // so that the current two-sided matrix is H_cur = Y Qt^T and its entries are 16-term dot products
@@ -262,31 +268,40 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // element-wise formulation `pair_inner_solve`.
 // Q is accumulated TRANSPOSED in S.Q during the pass (row p = column p of Q) and transposed back at the end.
 // kKeepQt: leave Q^T in S.Q (the caller's MFMA operand reads take the transposed index order for free).
-template <bool kKeepQt = false>
+// kMeasure = false: skip the convergence measure of the incoming H (tick3 lets an otherwise idle wave compute it
+// from the 32x32 image, `pair_measure_h32`) and rotate unconditionally; returns 0.
+template <bool kKeepQt = false, bool kMeasure = true>
 __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, int lane, double hmax, double tol,
                                                         bool within, double* __restrict__ hcur_out = nullptr) {
   double (*Hs)[kHP] = S.H;
   double (*Qs)[kHP] = S.Q;
+#ifdef TADMM_STAMPS
+  unsigned long long ts = clock64();
+#endif
   const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;
-  const float wscale = (float)(1e-14 / tol);
-  float mxf = 0.0f;
+  double mx = 0.0;
+  if (kMeasure) {
+    const float wscale = (float)(1e-14 / tol);
+    float mxf = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = lane * 4 + k;
-    const int i = e >> 4, j = e & 15;
-    if (i < j) {
-      const float ri = (float)(Hs[i][i] * inv_hmax), rj = (float)(Hs[j][j] * inv_hmax);
-      const float rmin = fminf(ri, rj);
-      if (rmin > 1e-28f) {
-        const float hij = fabsf((float)(Hs[i][j] * inv_hmax));
-        const float w = fmaxf(1.0f, wscale * __builtin_amdgcn_rsqf(rmin));
-        mxf = fmaxf(mxf, hij * __builtin_amdgcn_rsqf(ri) * __builtin_amdgcn_rsqf(rj) * __builtin_amdgcn_rcpf(w));
+    for (int k = 0; k < 4; ++k) {
+      const int e = lane * 4 + k;
+      const int i = e >> 4, j = e & 15;
+      if (i < j) {
+        const float ri = (float)(Hs[i][i] * inv_hmax), rj = (float)(Hs[j][j] * inv_hmax);
+        const float rmin = fminf(ri, rj);
+        if (rmin > 1e-28f) {
+          const float hij = fabsf((float)(Hs[i][j] * inv_hmax));
+          const float w = fmaxf(1.0f, wscale * __builtin_amdgcn_rsqf(rmin));
+          mxf = fmaxf(mxf, hij * __builtin_amdgcn_rsqf(ri) * __builtin_amdgcn_rsqf(rj) * __builtin_amdgcn_rcpf(w));
+        }
       }
     }
+    mx = (double)wave_max_f32(mxf);
   }
-  const double mx = (double)wave_max_f32(mxf);
+  SSTAMP(10);
   int did = 0;
-  if (mx > 1e-15) {
+  if (!kMeasure || mx > 1e-15) {
     const int g8 = lane >> 3, l8 = lane & 7;
     const double scale2 = inv_hmax;                       // entries of H_cur are ~lambda^2 <= hmax
     // rotation of rows (p,q) given the three entries a = h_pp, b = h_qq, g = h_pq of the current matrix
@@ -339,6 +354,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       *yp = vp; *tp = up;
       wave_lds_fence();
     }
+    SSTAMP(11);
     // within-block pairs (self pass only)
     for (int st = 0; within && st < kJB - 1; ++st) {
       int a2, b2;
@@ -389,6 +405,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
     for (int k = 0; k < 4; ++k) { const int e = lane * 4 + k; hcur_out[e] = Hs[e >> 4][e & 15]; }
   }
   if (lane == 0) *S.rotated = did;
+  SSTAMP(12);
   return mx;
 }
 
@@ -490,7 +507,6 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
 constexpr int kSuper = 2 * kPair;   // 32 rows in the slab
 
 #ifdef TADMM_STAMPS
-__device__ unsigned long long g_stamps[32];
 #define STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && tid == 0) g_stamps[i] += clock64() - t0; } while (0)
 #else
 #define STAMP(i) do {} while (0)
@@ -680,8 +696,33 @@ __device__ __forceinline__ void apply_q_tiles_store(const double* __restrict__ X
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], Xs[rowk[t] + col], acc, 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) XT[growk[e] + col] = acc[e];
+    for (int e = 0; e < 4; ++e) __hip_atomic_store(XT + growk[e] + col, acc[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// Convergence measure of the 16x16 subproblem (u,v) read from the 32x32 image (same formula as the preamble of
+// `pair_inner_solve_fast`); executed by a wave that is not solving, off the critical path.
+__device__ __forceinline__ double pair_measure_h32(const double (*H32)[kH32], int u, int v, int lane, double hmax,
+                                                   double tol) {
+  const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;
+  const float wscale = (float)(1e-14 / tol);
+  float mxf = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = lane * 4 + k;
+    const int i = e >> 4, j = e & 15;
+    if (i < j) {
+      const int gi = sub_index(u, v, i), gj = sub_index(u, v, j);
+      const float ri = (float)(H32[gi][gi] * inv_hmax), rj = (float)(H32[gj][gj] * inv_hmax);
+      const float rmin = fminf(ri, rj);
+      if (rmin > 1e-28f) {
+        const float hij = fabsf((float)(H32[gi][gj] * inv_hmax));
+        const float w = fmaxf(1.0f, wscale * __builtin_amdgcn_rsqf(rmin));
+        mxf = fmaxf(mxf, hij * __builtin_amdgcn_rsqf(ri) * __builtin_amdgcn_rsqf(rj) * __builtin_amdgcn_rcpf(w));
+      }
+    }
+  }
+  return (double)wave_max_f32(mxf);
 }
 
 // H32 <- Q^T H32 Q with Q = the two 16x16 rotations Qa (on the index set of sub-pair (ua,va)) and Qb (on (ub,vb)).
@@ -808,6 +849,7 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
 
   const double hmax = d.off[2];
   double mxall = 0.0;
+  const int mwave = (half + 2) & 3;                                 // the measuring wave of this half
   // ---- round 1: (0,2) | (1,3) ----
   {
     const int u = half ? 1 : 0, v = half ? 3 : 2;
@@ -817,7 +859,9 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
     if (wv == half) {      // waves 0 and 5: different SIMDs (waves 0 and 4 would share one)
       PairScratch S;
       S.H = Hs; S.Q = Q1; S.rotated = flags + half;
-      mxall = fmax(mxall, pair_inner_solve_fast<true>(S, lane, hmax, tol, false));
+      pair_inner_solve_fast<true, false>(S, lane, hmax, tol, false);
+    } else if (wv == mwave) {   // waves 2 and 7 (SIMDs 2 and 3): the convergence measure, off the critical path
+      mxall = pair_measure_h32(H32, u, v, lane, hmax, tol);
     }
     __syncthreads();
   }
@@ -838,9 +882,10 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
     PairScratch S;
     S.H = Hs; S.Q = Q2; S.rotated = flags + 2 + half;
     __builtin_amdgcn_s_setprio(3);        // the solve is the critical path; the updater waves have slack
-    mxall = fmax(mxall, pair_inner_solve_fast<true>(S, lane, hmax, tol, false));
+    pair_inner_solve_fast<true, false>(S, lane, hmax, tol, false);
     __builtin_amdgcn_s_setprio(0);
   } else {
+    if (wv == mwave) mxall = fmax(mxall, pair_measure_h32(H32, half ? 1 : 0, half ? 2 : 3, lane, hmax, tol));
     const int u = half ? 1 : 0, v = half ? 3 : 2;                   // this half's round-1 sub-pair
     const int wi = (wv > half) ? wv - 1 : wv;                       // 0..2 among the three non-solver waves
     if (flags[half]) apply_q_tiles(Xs, ldp, ld, Q1, u, v, wi, 3, lane);
@@ -848,7 +893,7 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   __syncthreads();
   STAMP(4);
   // ---- final self-Grams, then the round-2 column update straight from the MFMA accumulators to HBM ----
-  if (wv == half && lane == 0)
+  if (wv == mwave && lane == 0)
     atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mxall));
   const int any_rot = flags[0] | flags[1] | flags[2] | flags[3];
   if (!any_rot) return;
@@ -874,6 +919,7 @@ void dump_stamps() {
   unsigned long long h[32];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return;
   const double n = h[31] ? (double)h[31] : 1.0;
+  fprintf(stderr, "[stampsS] per launch (2 solves): preamble=%.0f loop=%.0f epilogue=%.0f\n", h[10] / n, h[11] / n, h[12] / n);
   fprintf(stderr, "[stamps3] launches=%llu cumulative: load=%.0f gram=%.0f solve1=%.0f xform=%.0f solve2||apply1=%.0f apply2+xform=%.0f end=%.0f\n",
           h[31], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n, h[20] / n);
   fprintf(stderr, "[stamps] launches=%llu  cumulative cycles/launch: load=%.0f", h[31], h[0] / n);
@@ -958,6 +1004,47 @@ __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restr
     }
     if (d.evec_out) d.evec_out[(int64_t)c * N + i] = v;
   }
+}
+
+// Convergence decision after a global sweep, on the device (one workgroup): a problem whose own sweep just ended
+// (tick % steps == 0) is finished when that sweep saw nothing above tol BEFORE rotating, or -- quadratic phase --
+// when the C*m^2 it leaves behind (C estimated from the last two sweeps, x10 safety) is below 10*tol, so no
+// sweep is spent just to observe it (post-sweep target 1e-8: eigenvector errors stay << 1e-5).  Finished
+// problems get their sticky `done` flag, which every later tick launch honours; *all_done tells the host.
+__global__ __launch_bounds__(256) void jacobi_conv_kernel(const EigDesc* __restrict__ descs, int nprob, int tick,
+                                                          double tol, int super, double* __restrict__ prev,
+                                                          int* __restrict__ all_done) {
+  __shared__ int open_problems;
+  if (threadIdx.x == 0) open_problems = 0;
+  __syncthreads();
+  for (int q = threadIdx.x; q < nprob; q += 256) {
+    const EigDesc d = descs[q];
+    if (*d.done) continue;
+    const int steps = (super ? (d.nb >> 1) : d.nb) - 1;
+    bool conv = false;
+    if (steps > 0 && tick % steps == 0) {
+      const int swp = tick / steps - 1;
+      const double m = d.off[swp & 1];
+      conv = m < tol;
+      const double mp = prev[q];
+      if (!conv && mp > 0.0 && mp < 1e-1 && m < 1e-3) {
+        const double C = 10.0 * fmax(1.0, m / (mp * mp));
+        conv = C * m * m < 10.0 * tol;
+      }
+      prev[q] = m;
+    }
+    if (conv) *d.done = 1;
+    else open_problems = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *all_done = open_problems ? 0 : 1;
+}
+
+void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,
+                        int* all_done_dev, hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(jacobi_conv_kernel, dim3(1), dim3(256), 0, s, descs_dev, nprob, tick, tol, super ? 1 : 0, prev_dev,
+                     all_done_dev);
 }
 
 void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s) {

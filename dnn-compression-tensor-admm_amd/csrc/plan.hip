@@ -177,12 +177,12 @@ struct StepPlan {
   int gsteps = 0;                 // ticks per global sweep = max(nb-1)
   size_t tick_lds = 0;            // dynamic LDS of the tick launches of this step
   int last_sweeps = 0;            // global sweeps the previous run needed (polls start 2 sweeps before that)
-  std::vector<double> prev_off;   // per problem: observed off-diagonal of its previous own sweep
   bool super = false;             // LDS-resident super-pair kernel (all problems of the level fit)
   int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 2: register/LDS cross kernel + self
   Phase eig_self;                 // mode 2: block map of the once-per-sweep self kernel (nb/2 workgroups per problem)
   int ld_max = 0;
   size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
+  size_t prev_off_dev = 0, alldone_off = 0;   // [neig] doubles of the convergence kernel / its verdict (int)
   std::vector<int> nb;            // per problem
   std::vector<int> layer_of;      // problem -> layer
 };
@@ -205,6 +205,9 @@ struct tadmm_plan_s {
   bool timing = false;
   hipEvent_t ev[16];
   bool ev_made = false;
+  hipEvent_t poll_ev[2];          // pipelined convergence poll: verdict of sweep g is read while sweep g+1 runs
+  int* poll_host = nullptr;       // pinned, 2 ints
+  bool poll_made = false;
   double last_ms[8] = {0};
   int last_sweeps = 0;
   // host staging for the poll
@@ -382,6 +385,8 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     sp.layer_of = layer_of;
     sp.off_off = ar.take((size_t)std::max(1, sp.neig) * 3 * 8);
     sp.done_off = ar.take((size_t)std::max(1, sp.neig) * 4);
+    sp.prev_off_dev = ar.take((size_t)std::max(1, sp.neig) * 8);
+    sp.alldone_off = ar.take(16);
     sp.gsteps = 0;
     for (int p = 0; p < sp.neig; ++p) {
       const int l = layer_of[p];
@@ -690,6 +695,12 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
   for (const StepPlan& sp : P->steps) maxe = std::max<size_t>(maxe, sp.neig);
   P->h_off.resize(maxe * 3);
   P->h_done.resize(maxe);
+  {
+    hipError_t e = hipHostMalloc((void**)&P->poll_host, 64, hipHostMallocDefault);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&P->poll_ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "poll buffers: %s", hipGetErrorString(e)); }
+    P->poll_made = true;
+  }
   *out = P;
   return TADMM_OK;
 }
@@ -746,10 +757,19 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     tic(0);
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
     launch_jacobi_init(ed, sp.neig, s);
-    sp.prev_off.assign(sp.neig, 0.0);
+    HIP_OK(h, hipMemsetAsync(D(sp.prev_off_dev), 0, (size_t)sp.neig * 8, s));
     bool all_done = false;
     int tick = 0;
     int gs = 0;
+    int pending = -1;       // global sweep whose verdict is in flight
+    int needed = 0;         // sweeps after which every problem was finished
+    auto consume = [&]() -> int {
+      if (pending < 0) return TADMM_OK;
+      if (hipEventSynchronize(p->poll_ev[pending & 1]) != hipSuccess) return TADMM_ERR_HIP;
+      if (p->poll_host[pending & 1]) { all_done = true; needed = pending + 1; }
+      pending = -1;
+      return TADMM_OK;
+    };
     for (; gs < p->max_global_sweeps && !all_done; ++gs) {
       for (int t = 0; t < sp.gsteps; ++t, ++tick) {
         if (sp.mode >= 2) {
@@ -769,43 +789,38 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
                              p->inner_sweeps, sp.tick_lds, sp.mode == 1, s);
         }
       }
-      // Convergence poll (one small D2H + stream sync).  Jacobi needs about the same number of sweeps
-      // from one ADMM iteration to the next, so sweeps that cannot be the last one are not polled.
-      if (gs + 3 < sp.last_sweeps) continue;
-      HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
-      HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
-      HIP_OK(h, hipStreamSynchronize(s));
-      all_done = true;
+      // Convergence: decided on the device after every sweep (jacobi_conv_kernel sets the sticky per-problem
+      // `done` flags, so finished problems cost nothing in later launches).  The host only needs "all finished?",
+      // and reads that verdict one sweep late: the copy of sweep g's verdict is consumed after sweep g+1 has been
+      // queued, so the GPU never idles on a poll; the price is one sweep of empty launches at the end.  Jacobi
+      // needs about the same number of sweeps from one ADMM iteration to the next, so the verdicts of sweeps that
+      // cannot be the last one are not even copied.
+      launch_jacobi_conv(ed, sp.neig, tick, p->tol, sp.super, (double*)D(sp.prev_off_dev), (int*)D(sp.alldone_off), s);
       if (p->debug) {
+        HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
+        HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
+        HIP_OK(h, hipStreamSynchronize(s));
         double mxo = 0; int nd = 0;
         for (int q = 0; q < sp.neig; ++q) {
-          if (p->h_done[q]) { ++nd; continue; }
           const int steps = sp.nb[q] - 1;
-          if (tick % steps == 0) mxo = std::max(mxo, p->h_off[3 * q + ((tick / steps - 1) & 1)]);
+          if (p->h_done[q]) ++nd;
+          if (steps > 0 && tick % steps == 0) mxo = std::max(mxo, p->h_off[3 * q + ((tick / steps - 1) & 1)]);
         }
         fprintf(stderr, "[tadmm]   sweep %d: max observed off %.3e, done %d/%d\n", gs, mxo, nd, sp.neig);
       }
-      for (int q = 0; q < sp.neig; ++q) {
-        if (p->h_done[q]) continue;
-        const int steps = sp.nb[q] - 1;
-        bool conv = false;
-        if (tick % steps == 0) {   // this problem just finished its own sweep number tick/steps - 1
-          const int swp = tick / steps - 1;
-          const double m = p->h_off[3 * q + (swp & 1)];       // largest off-diagonal the sweep saw BEFORE rotating
-          conv = m < p->tol;
-          // Quadratic phase: the sweep that observed m leaves about C*m^2 behind, C estimated from the last
-          // two sweeps (x10 safety).  Stop when that prediction is below the target instead of spending one
-          // more sweep just to observe it.
-          const double mp = sp.prev_off[q];
-          if (!conv && mp > 0.0 && mp < 1e-1 && m < 1e-3) {
-            const double C = 10.0 * std::max(1.0, m / (mp * mp));
-            conv = C * m * m < 10.0 * p->tol;      // post-sweep target 1e-8: eigenvector errors stay << 1e-5
-          }
-          sp.prev_off[q] = m;
-        }
-        if (!conv) all_done = false;
-      }
+      const int rc = consume();               // verdict of the previous polled sweep (long since on the host)
+      if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
+      if (all_done) { ++gs; break; }
+      if (gs + 3 < sp.last_sweeps) continue;
+      HIP_OK(h, hipMemcpyAsync(&p->poll_host[gs & 1], D(sp.alldone_off), 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(h, hipEventRecord(p->poll_ev[gs & 1], s));
+      pending = gs;
     }
+    if (!all_done) {
+      const int rc = consume();
+      if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
+    }
+    if (all_done) gs = needed;
     sp.last_sweeps = gs;
     total_sweeps += gs;
     if (p->debug) {
@@ -856,6 +871,10 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
 int tadmm_plan_destroy(tadmm_plan p) {
   if (!p) return TADMM_OK;
   if (p->ev_made) for (auto& e : p->ev) (void)hipEventDestroy(e);
+  if (p->poll_made) {
+    for (auto& e : p->poll_ev) (void)hipEventDestroy(e);
+    (void)hipHostFree(p->poll_host);
+  }
   delete p;
   return TADMM_OK;
 }
