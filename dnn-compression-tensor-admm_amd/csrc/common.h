@@ -70,9 +70,10 @@ struct EigDesc {
   double* sblk;       // [Npad/16][16*16] carried self-Gram of every 16-column super-block (tick3), nullable
 };
 void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s);
-// device-side convergence decision after a global sweep (prev_dev: [nprob] doubles, zeroed by the caller per run)
+// device-side convergence decision after a global sweep (prev_dev: [nprob] doubles, zeroed by the caller per run;
+// verdict_pinned: [1 + nprob] ints of device-visible pinned host memory)
 void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,
-                        int* all_done_dev, hipStream_t s);
+                        int* verdict_pinned, hipStream_t s);
 size_t jacobi_tick_lds_bytes(int ld_max);    // dynamic LDS of a tick1 launch whose largest problem has row length ld_max
 size_t jacobi_tick2_lds_bytes(int ld_max);   // same for the LDS-resident super-pair kernel
 bool jacobi_tick2_fits(int ld_max);

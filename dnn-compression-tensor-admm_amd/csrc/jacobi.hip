@@ -1013,13 +1013,15 @@ __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restr
 // problems get their sticky `done` flag, which every later tick launch honours; *all_done tells the host.
 __global__ __launch_bounds__(256) void jacobi_conv_kernel(const EigDesc* __restrict__ descs, int nprob, int tick,
                                                           double tol, int super, double* __restrict__ prev,
-                                                          int* __restrict__ all_done) {
+                                                          int* __restrict__ verdict) {
+  // verdict: pinned host memory, [0] = all finished, [1 + q] = problem q finished (visible to the host once the
+  // event recorded behind this launch has completed)
   __shared__ int open_problems;
   if (threadIdx.x == 0) open_problems = 0;
   __syncthreads();
   for (int q = threadIdx.x; q < nprob; q += 256) {
     const EigDesc d = descs[q];
-    if (*d.done) continue;
+    if (*d.done) { verdict[1 + q] = 1; continue; }
     const int steps = (super ? (d.nb >> 1) : d.nb) - 1;
     bool conv = false;
     if (steps > 0 && tick % steps == 0) {
@@ -1035,16 +1037,17 @@ __global__ __launch_bounds__(256) void jacobi_conv_kernel(const EigDesc* __restr
     }
     if (conv) *d.done = 1;
     else open_problems = 1;
+    verdict[1 + q] = conv ? 1 : 0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) *all_done = open_problems ? 0 : 1;
+  if (threadIdx.x == 0) verdict[0] = open_problems ? 0 : 1;
 }
 
 void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,
-                        int* all_done_dev, hipStream_t s) {
+                        int* verdict_pinned, hipStream_t s) {
   if (nprob <= 0) return;
   hipLaunchKernelGGL(jacobi_conv_kernel, dim3(1), dim3(256), 0, s, descs_dev, nprob, tick, tol, super ? 1 : 0, prev_dev,
-                     all_done_dev);
+                     verdict_pinned);
 }
 
 void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s) {

@@ -206,7 +206,8 @@ struct tadmm_plan_s {
   hipEvent_t ev[16];
   bool ev_made = false;
   hipEvent_t poll_ev[2];          // pipelined convergence poll: verdict of sweep g is read while sweep g+1 runs
-  int* poll_host = nullptr;       // pinned, 2 ints
+  int* poll_host = nullptr;       // pinned, 2 slots of (1 + max problems per level) ints, written by the device
+  size_t poll_stride = 0;
   bool poll_made = false;
   double last_ms[8] = {0};
   int last_sweeps = 0;
@@ -696,7 +697,8 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
   P->h_off.resize(maxe * 3);
   P->h_done.resize(maxe);
   {
-    hipError_t e = hipHostMalloc((void**)&P->poll_host, 64, hipHostMallocDefault);
+    P->poll_stride = (maxe + 1 + 15) & ~(size_t)15;
+    hipError_t e = hipHostMalloc((void**)&P->poll_host, 2 * P->poll_stride * sizeof(int), hipHostMallocDefault);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&P->poll_ev[i], hipEventDisableTiming);
     if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "poll buffers: %s", hipGetErrorString(e)); }
     P->poll_made = true;
@@ -762,11 +764,14 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     int tick = 0;
     int gs = 0;
     int pending = -1;       // global sweep whose verdict is in flight
+    std::vector<char> known_done(sp.neig, 0);   // what the host has learnt so far (lags the device by a sweep)
     int needed = 0;         // sweeps after which every problem was finished
     auto consume = [&]() -> int {
       if (pending < 0) return TADMM_OK;
       if (hipEventSynchronize(p->poll_ev[pending & 1]) != hipSuccess) return TADMM_ERR_HIP;
-      if (p->poll_host[pending & 1]) { all_done = true; needed = pending + 1; }
+      const int* v = p->poll_host + (size_t)(pending & 1) * p->poll_stride;
+      if (v[0]) { all_done = true; needed = pending + 1; }
+      for (int q = 0; q < sp.neig; ++q) known_done[q] = v[1 + q] != 0;
       pending = -1;
       return TADMM_OK;
     };
@@ -774,7 +779,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
       for (int t = 0; t < sp.gsteps; ++t, ++tick) {
         if (sp.mode >= 2) {
           bool any_first = false;     // does any problem start a sweep of its own at this tick?
-          for (int q = 0; q < sp.neig && !any_first; ++q) any_first = (tick % (sp.nb[q] - 1)) == 0;
+          for (int q = 0; q < sp.neig && !any_first; ++q) any_first = !known_done[q] && (tick % (sp.nb[q] - 1)) == 0;
           if (any_first)
             launch_jacobi_self(ed, (const BlockRef*)D(sp.eig_self.map_off), sp.eig_self.nblocks, tick, p->tol,
                                p->inner_sweeps, sp.ld_max, s);
@@ -792,10 +797,11 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
       // Convergence: decided on the device after every sweep (jacobi_conv_kernel sets the sticky per-problem
       // `done` flags, so finished problems cost nothing in later launches).  The host only needs "all finished?",
       // and reads that verdict one sweep late: the copy of sweep g's verdict is consumed after sweep g+1 has been
-      // queued, so the GPU never idles on a poll; the price is one sweep of empty launches at the end.  Jacobi
-      // needs about the same number of sweeps from one ADMM iteration to the next, so the verdicts of sweeps that
-      // cannot be the last one are not even copied.
-      launch_jacobi_conv(ed, sp.neig, tick, p->tol, sp.super, (double*)D(sp.prev_off_dev), (int*)D(sp.alldone_off), s);
+      // queued, so the GPU never idles on a poll; the price is one sweep of empty launches at the end.  The
+      // verdict (and the per-problem flags, which let the host stop launching the self pass for small problems
+      // that are long finished) is written by the kernel straight into pinned host memory: no copy in the stream.
+      launch_jacobi_conv(ed, sp.neig, tick, p->tol, sp.super, (double*)D(sp.prev_off_dev),
+                         p->poll_host + (size_t)(gs & 1) * p->poll_stride, s);
       if (p->debug) {
         HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
         HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
@@ -811,8 +817,6 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
       const int rc = consume();               // verdict of the previous polled sweep (long since on the host)
       if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
       if (all_done) { ++gs; break; }
-      if (gs + 3 < sp.last_sweeps) continue;
-      HIP_OK(h, hipMemcpyAsync(&p->poll_host[gs & 1], D(sp.alldone_off), 4, hipMemcpyDeviceToHost, s));
       HIP_OK(h, hipEventRecord(p->poll_ev[gs & 1], s));
       pending = gs;
     }
