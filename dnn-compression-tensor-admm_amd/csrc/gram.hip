@@ -37,6 +37,7 @@ __device__ __forceinline__ void tile_pair(int tp, int nt, int& ti, int& tj) {
 __global__ __launch_bounds__(256) void gram_partial_kernel(const GramDesc* __restrict__ descs,
                                                            const BlockRef* __restrict__ map) {
   __shared__ double red[4][4][64 * 4];  // [wave][tile][lane*4+reg]  32 KB
+  __shared__ double tile[32][33];       // summed 32x32 tile of the direct (ksplit == 1) path
   const BlockRef br = map[blockIdx.x];
   const GramDesc d = descs[br.prob];
   const int ntp = d.nt * (d.nt + 1) / 2;
@@ -60,83 +61,90 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const GramDesc* __res
   const int N = d.N;
   const int ra0 = ti * 32 + r, ra1 = ra0 + 16;   // G-rows of this lane for the A role
   const int rb0 = tj * 32 + r, rb1 = rb0 + 16;   // G-rows for the B role
+  const float ma0 = ra0 < N ? 1.f : 0.f, ma1 = ra1 < N ? 1.f : 0.f;
+  const float mb0 = rb0 < N ? 1.f : 0.f, mb1 = rb1 < N ? 1.f : 0.f;
+  const int64_t ld = d.n;
+
+  struct Chunk { float a0[4], a1[4], b0[4], b1[4]; };   // this lane's 4 reduction indices of a 16-wide k chunk
+  // 16 fp64 MFMAs per chunk; the next chunk's loads are issued before them (register double buffer), so the
+  // matrix cores do not wait for HBM/L2 latency
+  auto mma = [&](const Chunk& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double da0 = c.a0[e], da1 = c.a1[e];
+      const double db0 = diag ? da0 : (double)c.b0[e], db1 = diag ? da1 : (double)c.b1[e];
+      acc00 = mfma_f64(da0, db0, acc00);
+      acc01 = mfma_f64(da0, db1, acc01);
+      if (!diag) acc10 = mfma_f64(da1, db0, acc10);
+      acc11 = mfma_f64(da1, db1, acc11);
+    }
+  };
 
   if (!d.trans) {
-    // rows of A are G-indices, reduction runs along the contiguous dimension
-    const int64_t ld = d.n;
+    // rows of A are G-indices, reduction runs along the contiguous dimension; lane (r,q) takes k = kk+4q .. +3
+    // (a permutation of the MFMA k order that both operands share)
     const bool vec = ((ld & 3) == 0) && ((((uintptr_t)A) & 15) == 0);
     const float* pa0 = A + (int64_t)min(ra0, N - 1) * ld;
     const float* pa1 = A + (int64_t)min(ra1, N - 1) * ld;
     const float* pb0 = A + (int64_t)min(rb0, N - 1) * ld;
     const float* pb1 = A + (int64_t)min(rb1, N - 1) * ld;
-    const float ma0 = ra0 < N ? 1.f : 0.f, ma1 = ra1 < N ? 1.f : 0.f;
-    const float mb0 = rb0 < N ? 1.f : 0.f, mb1 = rb1 < N ? 1.f : 0.f;
-    for (int kk = wk0; kk < wk1; kk += 16) {
-      const int k = kk + 4 * q;  // this lane's 4 consecutive reduction indices (a permutation of the
-                                 // MFMA k order that both operands share)
-      float4 a0, a1, b0, b1;
+    auto fetch = [&](int kk, Chunk& c) {
+      const int k = kk + 4 * q;
       if (vec && k + 3 < wk1) {
-        a0 = *reinterpret_cast<const float4*>(pa0 + k);
-        a1 = *reinterpret_cast<const float4*>(pa1 + k);
+        const float4 t0 = *reinterpret_cast<const float4*>(pa0 + k);
+        const float4 t1 = *reinterpret_cast<const float4*>(pa1 + k);
+        c.a0[0] = t0.x * ma0; c.a0[1] = t0.y * ma0; c.a0[2] = t0.z * ma0; c.a0[3] = t0.w * ma0;
+        c.a1[0] = t1.x * ma1; c.a1[1] = t1.y * ma1; c.a1[2] = t1.z * ma1; c.a1[3] = t1.w * ma1;
         if (!diag) {
-          b0 = *reinterpret_cast<const float4*>(pb0 + k);
-          b1 = *reinterpret_cast<const float4*>(pb1 + k);
+          const float4 t2 = *reinterpret_cast<const float4*>(pb0 + k);
+          const float4 t3 = *reinterpret_cast<const float4*>(pb1 + k);
+          c.b0[0] = t2.x * mb0; c.b0[1] = t2.y * mb0; c.b0[2] = t2.z * mb0; c.b0[3] = t2.w * mb0;
+          c.b1[0] = t3.x * mb1; c.b1[1] = t3.y * mb1; c.b1[2] = t3.z * mb1; c.b1[3] = t3.w * mb1;
         }
       } else {
-        float t[4][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool ok = (k + e) < wk1;
-          t[0][e] = ok ? pa0[k + e] : 0.f;
-          t[1][e] = ok ? pa1[k + e] : 0.f;
-          t[2][e] = (ok && !diag) ? pb0[k + e] : 0.f;
-          t[3][e] = (ok && !diag) ? pb1[k + e] : 0.f;
+          c.a0[e] = ok ? pa0[k + e] * ma0 : 0.f;
+          c.a1[e] = ok ? pa1[k + e] * ma1 : 0.f;
+          c.b0[e] = (ok && !diag) ? pb0[k + e] * mb0 : 0.f;
+          c.b1[e] = (ok && !diag) ? pb1[k + e] * mb1 : 0.f;
         }
-        a0 = make_float4(t[0][0], t[0][1], t[0][2], t[0][3]);
-        a1 = make_float4(t[1][0], t[1][1], t[1][2], t[1][3]);
-        b0 = make_float4(t[2][0], t[2][1], t[2][2], t[2][3]);
-        b1 = make_float4(t[3][0], t[3][1], t[3][2], t[3][3]);
       }
-      a0.x *= ma0; a0.y *= ma0; a0.z *= ma0; a0.w *= ma0;
-      a1.x *= ma1; a1.y *= ma1; a1.z *= ma1; a1.w *= ma1;
-      if (diag) { b0 = a0; b1 = a1; } else {
-        b0.x *= mb0; b0.y *= mb0; b0.z *= mb0; b0.w *= mb0;
-        b1.x *= mb1; b1.y *= mb1; b1.z *= mb1; b1.w *= mb1;
-      }
-      const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-      const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double da0 = av0[e], da1 = av1[e], db0 = bv0[e], db1 = bv1[e];
-        acc00 = mfma_f64(da0, db0, acc00);
-        acc01 = mfma_f64(da0, db1, acc01);
-        if (!diag) acc10 = mfma_f64(da1, db0, acc10);
-        acc11 = mfma_f64(da1, db1, acc11);
+    };
+    if (wk0 < wk1) {
+      Chunk cur, nxt;
+      fetch(wk0, cur);
+      for (int kk = wk0; kk < wk1; kk += 16) {
+        const bool more = kk + 16 < wk1;
+        if (more) fetch(kk + 16, nxt);
+        mma(cur);
+        if (more) cur = nxt;
       }
     }
   } else {
-    // columns of A are G-indices, reduction runs over rows: lane (r,q) reads A[k+q][col]
-    const int64_t ld = d.n;
+    // columns of A are G-indices, reduction runs over rows: lane (r,q) reads A[kk+4e+q][col]
     const int ca0 = min(ra0, N - 1), ca1 = min(ra1, N - 1), cb0 = min(rb0, N - 1), cb1 = min(rb1, N - 1);
-    const float ma0 = ra0 < N ? 1.f : 0.f, ma1 = ra1 < N ? 1.f : 0.f;
-    const float mb0 = rb0 < N ? 1.f : 0.f, mb1 = rb1 < N ? 1.f : 0.f;
-    for (int kk = wk0; kk < wk1; kk += 16) {
+    auto fetch = [&](int kk, Chunk& c) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = kk + 4 * e + q;
         const bool ok = k < wk1;
         const float* row = A + (int64_t)min(k, d.K - 1) * ld;
-        const double da0 = ok ? row[ca0] * ma0 : 0.f;
-        const double da1 = ok ? row[ca1] * ma1 : 0.f;
-        double db0, db1;
-        if (diag) { db0 = da0; db1 = da1; } else {
-          db0 = ok ? row[cb0] * mb0 : 0.f;
-          db1 = ok ? row[cb1] * mb1 : 0.f;
-        }
-        acc00 = mfma_f64(da0, db0, acc00);
-        acc01 = mfma_f64(da0, db1, acc01);
-        if (!diag) acc10 = mfma_f64(da1, db0, acc10);
-        acc11 = mfma_f64(da1, db1, acc11);
+        c.a0[e] = ok ? row[ca0] * ma0 : 0.f;
+        c.a1[e] = ok ? row[ca1] * ma1 : 0.f;
+        c.b0[e] = (ok && !diag) ? row[cb0] * mb0 : 0.f;
+        c.b1[e] = (ok && !diag) ? row[cb1] * mb1 : 0.f;
+      }
+    };
+    if (wk0 < wk1) {
+      Chunk cur, nxt;
+      fetch(wk0, cur);
+      for (int kk = wk0; kk < wk1; kk += 16) {
+        const bool more = kk + 16 < wk1;
+        if (more) fetch(kk + 16, nxt);
+        mma(cur);
+        if (more) cur = nxt;
       }
     }
   }
@@ -150,14 +158,44 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const GramDesc* __res
     red[wave][3][lane * 4 + e] = acc11[e];
   }
   __syncthreads();
-  double* out = d.partial + ((int64_t)ks * ntp + tp) * 1024;
+  if (d.ksplit > 1) {
+    double* out = d.partial + ((int64_t)ks * ntp + tp) * 1024;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+      const int t = idx >> 8, le = idx & 255;        // tile, lane*4+reg
+      const double v = (red[0][t][le] + red[1][t][le]) + (red[2][t][le] + red[3][t][le]);
+      const int l = le >> 2, reg = le & 3;
+      const int row = (t >> 1) * 16 + (l >> 4) + 4 * reg;
+      const int col = (t & 1) * 16 + (l & 15);
+      out[row * 32 + col] = v;
+    }
+    return;
+  }
+  // direct path (no split-K): this workgroup owns the whole reduction, so it writes the tile and its mirror
+  // straight into the zero-padded [Npad][ld] image of the eigen-solver (Npad = 32*nt)
   for (int idx = threadIdx.x; idx < 1024; idx += 256) {
-    const int t = idx >> 8, le = idx & 255;        // tile, lane*4+reg
+    const int t = idx >> 8, le = idx & 255;
+    if (diag && t == 2) continue;                    // lower-left block of a diagonal tile = mirror of block 1
     const double v = (red[0][t][le] + red[1][t][le]) + (red[2][t][le] + red[3][t][le]);
     const int l = le >> 2, reg = le & 3;
     const int row = (t >> 1) * 16 + (l >> 4) + 4 * reg;
     const int col = (t & 1) * 16 + (l & 15);
-    out[row * 32 + col] = v;
+    tile[row][col] = v;
+    if (diag && t == 1) tile[col][row] = v;
+  }
+  __syncthreads();
+  double* __restrict__ G = d.G;
+  const int64_t gld = d.ld;
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    const int rr = e >> 5, cc = e & 31;
+    G[(int64_t)(ti * 32 + rr) * gld + tj * 32 + cc] = tile[rr][cc];
+    if (!diag) G[(int64_t)(tj * 32 + rr) * gld + ti * 32 + cc] = tile[cc][rr];
+  }
+  if (tj == d.nt - 1) {                              // zero the padding columns [Npad, ld) of row block ti
+    const int padw = d.ld - d.Npad;
+    for (int e = threadIdx.x; e < 32 * padw; e += 256) {
+      const int rr = e / padw, cc = e - rr * padw;
+      G[(int64_t)(ti * 32 + rr) * gld + d.Npad + cc] = 0.0;
+    }
   }
 }
 
@@ -180,7 +218,15 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const GramDesc* __rest
       if (a == b && jr > ir) { const int s = jr; jr = ir; ir = s; }   // diagonal tiles: upper part only
       const int tp = a * d.nt - (a * (a - 1)) / 2 + (b - a);
       const double* p = d.partial + (int64_t)tp * 1024 + jr * 32 + ir;
-      for (int ks = 0; ks < d.ksplit; ++ks) v += p[(int64_t)ks * ntp * 1024];
+      const int64_t stride = (int64_t)ntp * 1024;
+      int ks = 0;
+      for (; ks + 8 <= d.ksplit; ks += 8) {          // independent loads in flight; the order of the adds is fixed
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(ks + u) * stride];
+        v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+      }
+      for (; ks < d.ksplit; ++ks) v += p[ks * stride];
     }
     d.G[idx] = v;
   }

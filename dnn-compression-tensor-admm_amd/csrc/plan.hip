@@ -138,9 +138,14 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
                "TT step %d: eigen-problem of size %d exceeds the LDS-resident Jacobi kernels (max ~1270)", s, st.N);
     const int64_t K = st.trans ? st.m : st.cols;
     const int ntp = st.nt * (st.nt + 1) / 2;
-    int ks = (256 + ntp - 1) / ntp;   // ~256 workgroups per problem; levels batch 15-30 problems
+    // split-K only where a problem has too few tiles to matter beside the others of its level (levels batch
+    // 15-30 problems): >= 64 workgroups per problem; big problems (ks = 1) write G directly, no reduce pass
+    int ks = (64 + ntp - 1) / ntp;
     const int maxks = (int)std::max<int64_t>(1, (K + 255) / 256);
     ks = std::max(1, std::min(ks, maxks));
+    // a workgroup's duration grows with its K chunk and it shares the CU's matrix cores with its neighbours:
+    // cap the chunk so that the long reductions (K = 4608 beside K = 512) do not form the tail of the launch
+    ks = std::max(ks, (int)((K + 2047) / 2048));
     st.kchunk = (int)align_up((K + ks - 1) / ks, 64);
     st.ksplit = (int)((K + st.kchunk - 1) / st.kchunk);
   }
@@ -370,6 +375,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     std::vector<EigDesc> ed;
     std::vector<GemmDesc> pd;
     std::vector<BlockRef> m_gp, m_gr, m_tick, m_norm, m_ext, m_proj;
+    std::vector<int> gp_cost;     // per problem: K chunk of its Gram workgroups (longest first in the block map)
     std::vector<int> layer_of;
     for (int l = 0; l < n; ++l) {
       const LayerGeom& g = P->layers[l];
@@ -421,8 +427,10 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       gdsc.Npad = st.Npad; gdsc.ld = st.ld;
       const int ntp = st.nt * (st.nt + 1) / 2;
       for (int b = 0; b < st.ksplit * ntp; ++b) m_gp.push_back(BlockRef{p, b});
+      gp_cost.push_back(st.kchunk);
       const int64_t gtot = (int64_t)st.Npad * st.ld;
-      for (int b = 0; b < (int)((gtot + 1023) / 1024); ++b) m_gr.push_back(BlockRef{p, b});
+      if (st.ksplit > 1)
+        for (int b = 0; b < (int)((gtot + 1023) / 1024); ++b) m_gr.push_back(BlockRef{p, b});
       gd.push_back(gdsc);
       // eig
       EigDesc e;
@@ -484,6 +492,8 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
         if (!map.empty()) img->put(ph.map_off, map.data(), map.size() * sizeof(BlockRef));
       }
     };
+    std::stable_sort(m_gp.begin(), m_gp.end(),
+                     [&](const BlockRef& a, const BlockRef& b) { return gp_cost[a.prob] > gp_cost[b.prob]; });
     place(sp.gram_p, gd.data(), gd.size() * sizeof(GramDesc), sp.neig, m_gp);
     sp.gram_r = sp.gram_p;
     sp.gram_r.map_off = da.take(std::max<size_t>(m_gr.size() * sizeof(BlockRef), 16));
@@ -1000,7 +1010,8 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
   GramDesc* gdev = (GramDesc*)(base + off); off += align_up(sizeof(GramDesc), 256);
   std::vector<BlockRef> mp, mr;
   for (int b = 0; b < (int)(st.ksplit * ntp); ++b) mp.push_back(BlockRef{0, b});
-  for (int b = 0; b < (int)(((size_t)st.Npad * st.ld + 1023) / 1024); ++b) mr.push_back(BlockRef{0, b});
+  if (st.ksplit > 1)   // ksplit == 1: the product kernel writes G itself
+    for (int b = 0; b < (int)(((size_t)st.Npad * st.ld + 1023) / 1024); ++b) mr.push_back(BlockRef{0, b});
   BlockRef* mpd = (BlockRef*)(base + off); off += align_up(mp.size() * sizeof(BlockRef), 256);
   BlockRef* mrd = (BlockRef*)(base + off);
   GramDesc gd;

@@ -11,3 +11,7 @@ for k, v in sorted(gap.items(), key=lambda kv: -sum(kv[1]))[:10]:
     v2 = sorted(v); print("gap %-26s -> %-26s n=%5d  median %.2f us  mean %.2f us  p90 %.2f  total %.2f ms" % (k[0], k[1], len(v), v2[len(v)//2] / 1e3, sum(v) / len(v) / 1e3, v2[int(len(v)*0.9)] / 1e3, sum(v) / 1e6))
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:6]:
     v2 = sorted(v); print("dur %-26s n=%5d median %.2f us mean %.2f us total %.2f ms" % (k, len(v), v2[len(v)//2] / 1e3, sum(v) / len(v) / 1e3, sum(v) / 1e6))
+if len(sys.argv) > 2:
+    pat = sys.argv[2]
+    sel = [(s, e, n) for s, e, n in rows if pat in n]
+    print("per-launch durations (us) of", pat, ":", " ".join("%.1f" % ((e - s) / 1e3) for s, e, n in sel[-16:]))
