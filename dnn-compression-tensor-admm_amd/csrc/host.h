@@ -1,0 +1,177 @@
+// Host-side pieces shared by the plan builders (plan.hip: TT / SVD projection, tucker_plan.hip: Tucker-2):
+// the context object behind tadmm_handle, error macros, the two-pass workspace arena, the XCD-aware block
+// order of the Jacobi tournament, and the driver loop of one grouped eigen-solve.
+#pragma once
+#include "common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct tadmm_ctx_s {
+  int device = 0;
+  std::string err;
+};
+
+#define CTX_FAIL(h, code, ...)                                   \
+  do {                                                           \
+    char _b[512];                                                \
+    snprintf(_b, sizeof _b, __VA_ARGS__);                        \
+    if (h) (h)->err = _b;                                        \
+    return (code);                                               \
+  } while (0)
+
+#define HIP_OK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (call);                                                                          \
+    if (_e != hipSuccess) CTX_FAIL(h, TADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+
+namespace tadmm {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH "Workgroup
+// dispatch").  Re-order a block map so that CONSECUTIVE logical blocks land on the same XCD: the tournament
+// hands a super-block from workgroup q to q+-1 between launches, so the next launch finds it in that XCD's L2.
+static inline void xcd_group(std::vector<BlockRef>& m) {
+  const char* e = getenv("TADMM_XCD_MAP");   // default on; 0 = plain order (for A/B measurements)
+  if (e && !atoi(e)) return;
+  const int G = (int)m.size();
+  if (G < 16) return;
+  std::vector<BlockRef> out(G);
+  int i = 0;
+  for (int x = 0; x < 8; ++x)
+    for (int b = x; b < G; b += 8) out[b] = m[i++];
+  m.swap(out);
+}
+
+// Which Jacobi kernel a group of problems whose longest row is ld_max uses:
+// 3 = tick3 (carried self-Grams) + self pass, 2 = experimental cross kernel + self pass, 1 = LDS super-pair,
+// 0 = plain pair kernel.  TADMM_JACOBI_MODE overrides the preference, never the capacity checks.
+static inline int choose_jacobi_mode(int ld_max) {
+  const char* em = getenv("TADMM_JACOBI_MODE");
+  int want = em ? atoi(em) : 3;
+  if (want == 3 && (!jacobi_tick3_fits(ld_max) || ld_max % 64)) want = 1;
+  if (want == 2 && (ld_max > jacobi_cross_max_ld() || ld_max % 128)) want = 1;
+  if (want == 1 && !jacobi_tick2_fits(ld_max)) want = 0;
+  return want;
+}
+
+// Pinned verdict slots + events of the pipelined convergence poll (one per plan).
+struct PollCtx {
+  hipEvent_t ev[2];
+  int* host = nullptr;      // 2 slots of `stride` ints, written by jacobi_conv_kernel
+  size_t stride = 0;
+  bool made = false;
+  hipError_t create(size_t max_problems) {
+    stride = (max_problems + 1 + 15) & ~(size_t)15;
+    hipError_t e = hipHostMalloc((void**)&host, 2 * stride * sizeof(int), hipHostMallocDefault);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    made = e == hipSuccess;
+    return e;
+  }
+  void destroy() {
+    if (!made) return;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipHostFree(host);
+    made = false;
+  }
+};
+
+// One grouped eigen-solve: `neig` symmetric problems whose descriptors / block maps already sit on the device.
+struct EigGroup {
+  const EigDesc* ed = nullptr;
+  int neig = 0;
+  const int* players = nullptr;     // per problem: tournament players (super-blocks or blocks)
+  int gsteps = 0;                   // ticks per global sweep = max(players - 1)
+  int mode = 0;
+  int ld_max = 0;
+  size_t tick_lds = 0;
+  const BlockRef* tick_map = nullptr; int tick_blocks = 0;
+  const BlockRef* self_map = nullptr; int self_blocks = 0;
+  double* prev_dev = nullptr;       // [neig] scratch of the convergence kernel
+  // debug only
+  const double* off_dev = nullptr; const int* done_dev = nullptr;
+};
+
+// Runs jacobi_init + sweeps until every problem of the group has its `done` flag.
+// Convergence is decided on the device after every sweep (jacobi_conv_kernel sets the sticky per-problem flags,
+// so finished problems cost nothing in later launches).  The host only needs "all finished?" and reads that
+// verdict one sweep late: the verdict of sweep g (written by the kernel straight into pinned host memory -- no
+// copy in the stream) is consumed after sweep g+1 has been queued, so the GPU never idles on a poll; the price
+// is one sweep of empty launches at the end.  The per-problem flags let the host stop launching the self pass
+// for small problems that are long finished.
+static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll, double tol, int inner_sweeps,
+                                int max_sweeps, bool debug, hipStream_t s, int* sweeps_out) {
+  *sweeps_out = 0;
+  if (g.neig == 0) return TADMM_OK;
+  launch_jacobi_init(g.ed, g.neig, s);
+  HIP_OK(h, hipMemsetAsync(g.prev_dev, 0, (size_t)g.neig * 8, s));
+  if (g.gsteps == 0) return TADMM_OK;      // every problem is a single block: nothing to rotate
+  bool all_done = false;
+  int tick = 0, gs = 0, pending = -1, needed = 0;
+  std::vector<char> known_done(g.neig, 0);   // what the host has learnt so far (lags the device by a sweep)
+  std::vector<double> h_off;
+  std::vector<int> h_done;
+  auto consume = [&]() -> int {
+    if (pending < 0) return TADMM_OK;
+    if (hipEventSynchronize(poll.ev[pending & 1]) != hipSuccess) return TADMM_ERR_HIP;
+    const int* v = poll.host + (size_t)(pending & 1) * poll.stride;
+    if (v[0]) { all_done = true; needed = pending + 1; }
+    for (int q = 0; q < g.neig; ++q) known_done[q] = v[1 + q] != 0;
+    pending = -1;
+    return TADMM_OK;
+  };
+  for (; gs < max_sweeps && !all_done; ++gs) {
+    for (int t = 0; t < g.gsteps; ++t, ++tick) {
+      if (g.mode >= 2) {
+        bool any_first = false;     // does any unfinished problem start a sweep of its own at this tick?
+        for (int q = 0; q < g.neig && !any_first; ++q)
+          any_first = !known_done[q] && g.players[q] > 1 && (tick % (g.players[q] - 1)) == 0;
+        if (any_first) launch_jacobi_self(g.ed, g.self_map, g.self_blocks, tick, tol, inner_sweeps, g.ld_max, s);
+        if (g.mode == 3) launch_jacobi_tick3(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
+        else launch_jacobi_cross(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
+      } else {
+        launch_jacobi_tick(g.ed, g.tick_map, g.tick_blocks, tick, tol, inner_sweeps, g.tick_lds, g.mode == 1, s);
+      }
+    }
+    launch_jacobi_conv(g.ed, g.neig, tick, tol, g.mode >= 1, g.prev_dev, poll.host + (size_t)(gs & 1) * poll.stride, s);
+    if (debug && g.off_dev) {
+      h_off.resize((size_t)g.neig * 3); h_done.resize(g.neig);
+      HIP_OK(h, hipMemcpyAsync(h_off.data(), g.off_dev, (size_t)g.neig * 3 * 8, hipMemcpyDeviceToHost, s));
+      HIP_OK(h, hipMemcpyAsync(h_done.data(), g.done_dev, (size_t)g.neig * 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(h, hipStreamSynchronize(s));
+      double mxo = 0; int nd = 0;
+      for (int q = 0; q < g.neig; ++q) {
+        const int steps = g.players[q] - 1;
+        if (h_done[q]) ++nd;
+        if (steps > 0 && tick % steps == 0) mxo = std::max(mxo, h_off[3 * q + ((tick / steps - 1) & 1)]);
+      }
+      fprintf(stderr, "[tadmm]   sweep %d: max observed off %.3e, done %d/%d\n", gs, mxo, nd, g.neig);
+    }
+    const int rc = consume();               // verdict of the previous sweep (long since on the host)
+    if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
+    if (all_done) break;
+    HIP_OK(h, hipEventRecord(poll.ev[gs & 1], s));
+    pending = gs;
+  }
+  if (!all_done) {
+    const int rc = consume();
+    if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
+  }
+  if (debug) {
+    int pmax = 0;
+    for (int q = 0; q < g.neig; ++q) pmax = std::max(pmax, g.players[q]);
+    fprintf(stderr, "[tadmm] eig group: neig=%d players_max=%d ticks/sweep=%d wgs/tick=%d sweeps=%d ticks=%d mode=%d\n",
+            g.neig, pmax, g.gsteps, g.tick_blocks, all_done ? needed : gs, tick, g.mode);
+  }
+  if (!all_done) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in %d sweeps", max_sweeps);
+  *sweeps_out = needed;
+  return TADMM_OK;
+}
+
+}  // namespace tadmm

@@ -13,38 +13,11 @@
 // Layers are independent, so every launch is *grouped*: its blocks are mapped to
 // (layer, local block) through a BlockRef table built once at plan creation.  All descriptors live in
 // the caller-provided workspace; tadmm_plan_run allocates nothing.
-#include "common.h"
+#include "host.h"
 
-#include <algorithm>
 #include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
 
 using namespace tadmm;
-
-struct tadmm_ctx_s {
-  int device = 0;
-  std::string err;
-};
-
-#define CTX_FAIL(h, code, ...)                                   \
-  do {                                                           \
-    char _b[512];                                                \
-    snprintf(_b, sizeof _b, __VA_ARGS__);                        \
-    if (h) (h)->err = _b;                                        \
-    return (code);                                               \
-  } while (0)
-
-#define HIP_OK(h, call)                                                                              \
-  do {                                                                                               \
-    hipError_t _e = (call);                                                                          \
-    if (_e != hipSuccess) CTX_FAIL(h, TADMM_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
-  } while (0)
-
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
 // layer geometry
@@ -155,21 +128,6 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH "Workgroup
-// dispatch").  Re-order a block map so that CONSECUTIVE logical blocks land on the same XCD: the tournament
-// hands a super-block from workgroup q to q+-1 between launches, so the next launch finds it in that XCD's L2.
-static void xcd_group(std::vector<BlockRef>& m) {
-  const char* e = getenv("TADMM_XCD_MAP");   // default on; 0 = plain order (for A/B measurements)
-  if (e && !atoi(e)) return;
-  const int G = (int)m.size();
-  if (G < 16) return;
-  std::vector<BlockRef> out(G);
-  int i = 0;
-  for (int x = 0; x < 8; ++x)
-    for (int b = x; b < G; b += 8) out[b] = m[i++];
-  m.swap(out);
-}
-
 struct Phase {  // one grouped launch: descriptor array + block map inside the device arena
   size_t desc_off = 0, map_off = 0;
   int nprob = 0, nblocks = 0;
@@ -210,10 +168,7 @@ struct tadmm_plan_s {
   bool timing = false;
   hipEvent_t ev[16];
   bool ev_made = false;
-  hipEvent_t poll_ev[2];          // pipelined convergence poll: verdict of sweep g is read while sweep g+1 runs
-  int* poll_host = nullptr;       // pinned, 2 slots of (1 + max problems per level) ints, written by the device
-  size_t poll_stride = 0;
-  bool poll_made = false;
+  PollCtx poll;                   // pipelined convergence poll (host.h)
   double last_ms[8] = {0};
   int last_sweeps = 0;
   // host staging for the poll
@@ -501,11 +456,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     if (img && !m_gr.empty()) img->put(sp.gram_r.map_off, m_gr.data(), m_gr.size() * sizeof(BlockRef));
     // tick shape of the level: LDS-resident super-pairs when every problem fits, else plain pairs
     {
-      const char* em = getenv("TADMM_JACOBI_MODE");
-      int want = em ? atoi(em) : 3;
-      if (want == 3 && (!jacobi_tick3_fits(sp.ld_max) || sp.ld_max % 64)) want = 1;
-      if (want == 2 && (sp.ld_max > jacobi_cross_max_ld() || sp.ld_max % 128)) want = 1;
-      if (want == 1 && !jacobi_tick2_fits(sp.ld_max)) want = 0;
+      const int want = choose_jacobi_mode(sp.ld_max);
       sp.mode = sp.neig > 0 ? want : 0;
     }
     sp.super = sp.mode >= 1;
@@ -707,11 +658,8 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
   P->h_off.resize(maxe * 3);
   P->h_done.resize(maxe);
   {
-    P->poll_stride = (maxe + 1 + 15) & ~(size_t)15;
-    hipError_t e = hipHostMalloc((void**)&P->poll_host, 2 * P->poll_stride * sizeof(int), hipHostMallocDefault);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&P->poll_ev[i], hipEventDisableTiming);
+    const hipError_t e = P->poll.create(maxe);
     if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "poll buffers: %s", hipGetErrorString(e)); }
-    P->poll_made = true;
   }
   *out = P;
   return TADMM_OK;
@@ -768,83 +716,20 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     toc(0, 1);
     tic(0);
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
-    launch_jacobi_init(ed, sp.neig, s);
-    HIP_OK(h, hipMemsetAsync(D(sp.prev_off_dev), 0, (size_t)sp.neig * 8, s));
-    bool all_done = false;
-    int tick = 0;
+    EigGroup eg;
+    eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode;
+    eg.ld_max = sp.ld_max; eg.tick_lds = sp.tick_lds;
+    eg.tick_map = (const BlockRef*)D(sp.eig_tick.map_off); eg.tick_blocks = sp.eig_tick.nblocks;
+    eg.self_map = (const BlockRef*)D(sp.eig_self.map_off); eg.self_blocks = sp.eig_self.nblocks;
+    eg.prev_dev = (double*)D(sp.prev_off_dev);
+    eg.off_dev = (const double*)D(sp.off_off); eg.done_dev = (const int*)D(sp.done_off);
     int gs = 0;
-    int pending = -1;       // global sweep whose verdict is in flight
-    std::vector<char> known_done(sp.neig, 0);   // what the host has learnt so far (lags the device by a sweep)
-    int needed = 0;         // sweeps after which every problem was finished
-    auto consume = [&]() -> int {
-      if (pending < 0) return TADMM_OK;
-      if (hipEventSynchronize(p->poll_ev[pending & 1]) != hipSuccess) return TADMM_ERR_HIP;
-      const int* v = p->poll_host + (size_t)(pending & 1) * p->poll_stride;
-      if (v[0]) { all_done = true; needed = pending + 1; }
-      for (int q = 0; q < sp.neig; ++q) known_done[q] = v[1 + q] != 0;
-      pending = -1;
-      return TADMM_OK;
-    };
-    for (; gs < p->max_global_sweeps && !all_done; ++gs) {
-      for (int t = 0; t < sp.gsteps; ++t, ++tick) {
-        if (sp.mode >= 2) {
-          bool any_first = false;     // does any problem start a sweep of its own at this tick?
-          for (int q = 0; q < sp.neig && !any_first; ++q) any_first = !known_done[q] && (tick % (sp.nb[q] - 1)) == 0;
-          if (any_first)
-            launch_jacobi_self(ed, (const BlockRef*)D(sp.eig_self.map_off), sp.eig_self.nblocks, tick, p->tol,
-                               p->inner_sweeps, sp.ld_max, s);
-          if (sp.mode == 3)
-            launch_jacobi_tick3(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
-                                sp.ld_max, s);
-          else
-            launch_jacobi_cross(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
-                                sp.ld_max, s);
-        } else {
-          launch_jacobi_tick(ed, (const BlockRef*)D(sp.eig_tick.map_off), sp.eig_tick.nblocks, tick, p->tol,
-                             p->inner_sweeps, sp.tick_lds, sp.mode == 1, s);
-        }
-      }
-      // Convergence: decided on the device after every sweep (jacobi_conv_kernel sets the sticky per-problem
-      // `done` flags, so finished problems cost nothing in later launches).  The host only needs "all finished?",
-      // and reads that verdict one sweep late: the copy of sweep g's verdict is consumed after sweep g+1 has been
-      // queued, so the GPU never idles on a poll; the price is one sweep of empty launches at the end.  The
-      // verdict (and the per-problem flags, which let the host stop launching the self pass for small problems
-      // that are long finished) is written by the kernel straight into pinned host memory: no copy in the stream.
-      launch_jacobi_conv(ed, sp.neig, tick, p->tol, sp.super, (double*)D(sp.prev_off_dev),
-                         p->poll_host + (size_t)(gs & 1) * p->poll_stride, s);
-      if (p->debug) {
-        HIP_OK(h, hipMemcpyAsync(p->h_off.data(), D(sp.off_off), (size_t)sp.neig * 3 * 8, hipMemcpyDeviceToHost, s));
-        HIP_OK(h, hipMemcpyAsync(p->h_done.data(), D(sp.done_off), (size_t)sp.neig * 4, hipMemcpyDeviceToHost, s));
-        HIP_OK(h, hipStreamSynchronize(s));
-        double mxo = 0; int nd = 0;
-        for (int q = 0; q < sp.neig; ++q) {
-          const int steps = sp.nb[q] - 1;
-          if (p->h_done[q]) ++nd;
-          if (steps > 0 && tick % steps == 0) mxo = std::max(mxo, p->h_off[3 * q + ((tick / steps - 1) & 1)]);
-        }
-        fprintf(stderr, "[tadmm]   sweep %d: max observed off %.3e, done %d/%d\n", gs, mxo, nd, sp.neig);
-      }
-      const int rc = consume();               // verdict of the previous polled sweep (long since on the host)
-      if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
-      if (all_done) { ++gs; break; }
-      HIP_OK(h, hipEventRecord(p->poll_ev[gs & 1], s));
-      pending = gs;
+    {
+      const int rc = run_eig_group(h, eg, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &gs);
+      if (rc != TADMM_OK) return rc;
     }
-    if (!all_done) {
-      const int rc = consume();
-      if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
-    }
-    if (all_done) gs = needed;
     sp.last_sweeps = gs;
     total_sweeps += gs;
-    if (p->debug) {
-      (void)hipStreamSynchronize(s);
-      int nbmax = 0, nbig = 0; long wgs = sp.eig_tick.nblocks;
-      for (int q = 0; q < sp.neig; ++q) { nbmax = std::max(nbmax, sp.nb[q]); nbig += sp.nb[q] >= 32; }
-      fprintf(stderr, "[tadmm] step: neig=%d (nb>=32: %d) nbmax=%d ticks/sweep=%d wgs/tick=%ld sweeps=%d ticks=%d lds=%zu\n",
-              sp.neig, nbig, nbmax, sp.gsteps, wgs, gs, tick, sp.tick_lds);
-    }
-    if (!all_done) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in %d sweeps", p->max_global_sweeps);
     launch_eig_norms(ed, (const BlockRef*)D(sp.eig_norm.map_off), sp.eig_norm.nblocks, s);
     launch_eig_sort(ed, sp.neig, s);
     launch_eig_extract(ed, (const BlockRef*)D(sp.eig_ext.map_off), sp.eig_ext.nblocks, s);
@@ -885,10 +770,7 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
 int tadmm_plan_destroy(tadmm_plan p) {
   if (!p) return TADMM_OK;
   if (p->ev_made) for (auto& e : p->ev) (void)hipEventDestroy(e);
-  if (p->poll_made) {
-    for (auto& e : p->poll_ev) (void)hipEventDestroy(e);
-    (void)hipHostFree(p->poll_host);
-  }
+  p->poll.destroy();
   delete p;
   return TADMM_OK;
 }
