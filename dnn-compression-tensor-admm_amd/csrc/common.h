@@ -47,8 +47,12 @@ struct GramDesc {
   double* G;          // [Npad][ld]  (row j = column j of the symmetric matrix), zero padded
   int32_t Npad, ld;
 };
-void launch_gram_partial(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
-void launch_gram_reduce(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+// `skip` (nullable, here and below): device int per problem; a non-zero entry turns every block of that problem
+// into a no-op.  Lets a data-dependent outer loop (Tucker HOOI) drop finished layers without rebuilding maps.
+void launch_gram_partial(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                         const int32_t* skip = nullptr);
+void launch_gram_reduce(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                        const int32_t* skip = nullptr);
 
 // ---------------------------------------------------------------- Jacobi eigen-solver
 constexpr int kJB = 8;          // columns per block; a pair is 2*kJB = 16 columns = one MFMA tile
@@ -64,12 +68,14 @@ struct EigDesc {
   int32_t r;          // kept rank
   int32_t mode;       // 0: left vectors  (m<=n): Uf[m][r] = V           (core), needs project GEMM
                       // 1: right vectors (m>n) : Vs[n][r] = V/sigma, Tn[r][n] = sigma*V^T ; 2: evec_out only
+                      // 3: out_a = V/sigma only
   float* out_a;       // mode0: Uf (N x r) ; mode1: Vs (N x r)
   float* out_b;       // mode1: Tnext (r x N) ; mode0: unused
   double* evec_out;   // optional: [r][N] eigenvectors as rows in fp64 (tadmm_eigh_f64), nullable
   double* sblk;       // [Npad/16][16*16] carried self-Gram of every 16-column super-block (tick3), nullable
+  int32_t ldo;        // leading dimension of out_a (0: r)
 };
-void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s);
+void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr);
 // device-side convergence decision after a global sweep (prev_dev: [nprob] doubles, zeroed by the caller per run;
 // verdict_pinned: [1 + nprob] ints of device-visible pinned host memory)
 void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,
@@ -95,9 +101,11 @@ void launch_jacobi_cross(const EigDesc* descs_dev, const BlockRef* map_dev, int 
                          int ld_max, hipStream_t s);
 void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, int ld_max, hipStream_t s);
-void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
-void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s);
-void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                      const int32_t* skip = nullptr);
+void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr);
+void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                        const int32_t* skip = nullptr);
 
 // ---------------------------------------------------------------- grouped GEMM (fp32 MFMA)
 struct GemmDesc {
@@ -109,7 +117,8 @@ struct GemmDesc {
   int32_t tiles_m, tiles_n;
 };
 constexpr int kGemmBM = 64, kGemmBN = 64;
-void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                 const int32_t* skip = nullptr);
 
 // ---------------------------------------------------------------- penalty
 constexpr int kPenaltyBlocks = 1024;

@@ -68,10 +68,12 @@ __device__ __forceinline__ void store_tile4(float* __restrict__ S, int ldS, bool
 }
 
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ descs,
-                                                   const BlockRef* __restrict__ map) {
+                                                   const BlockRef* __restrict__ map,
+                                                   const int32_t* __restrict__ skip) {
   __shared__ __attribute__((aligned(16))) float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   const BlockRef br = map[blockIdx.x];
+  if (skip && skip[br.prob]) return;
   const GemmDesc d = descs[br.prob];
   const int tm = br.local / d.tiles_n, tn = br.local - tm * d.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ 
   }
 }
 
-void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, const int32_t* skip) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(gemm_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  hipLaunchKernelGGL(gemm_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
 
 }  // namespace tadmm

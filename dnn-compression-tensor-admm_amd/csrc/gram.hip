@@ -35,10 +35,12 @@ __device__ __forceinline__ void tile_pair(int tp, int nt, int& ti, int& tj) {
 }
 
 __global__ __launch_bounds__(256) void gram_partial_kernel(const GramDesc* __restrict__ descs,
-                                                           const BlockRef* __restrict__ map) {
+                                                           const BlockRef* __restrict__ map,
+                                                           const int32_t* __restrict__ skip) {
   __shared__ double red[4][4][64 * 4];  // [wave][tile][lane*4+reg]  32 KB
   __shared__ double tile[32][33];       // summed 32x32 tile of the direct (ksplit == 1) path
   const BlockRef br = map[blockIdx.x];
+  if (skip && skip[br.prob]) return;
   const GramDesc d = descs[br.prob];
   const int ntp = d.nt * (d.nt + 1) / 2;
   const int ks = br.local / ntp;
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const GramDesc* __res
 
 // sum split-K partials, mirror, zero-pad.  local block = chunk of 1024 outputs of the [Npad][ld] image
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const GramDesc* __restrict__ descs,
-                                                          const BlockRef* __restrict__ map) {
+                                                          const BlockRef* __restrict__ map,
+                                                          const int32_t* __restrict__ skip) {
   const BlockRef br = map[blockIdx.x];
+  if (skip && skip[br.prob]) return;
   const GramDesc d = descs[br.prob];
   const int ntp = d.nt * (d.nt + 1) / 2;
   const int64_t total = (int64_t)d.Npad * d.ld;
@@ -232,14 +236,16 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const GramDesc* __rest
   }
 }
 
-void launch_gram_partial(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+void launch_gram_partial(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                         const int32_t* skip) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
 
-void launch_gram_reduce(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+void launch_gram_reduce(const GramDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                        const int32_t* skip) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
 
 }  // namespace tadmm

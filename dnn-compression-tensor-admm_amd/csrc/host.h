@@ -94,6 +94,7 @@ struct EigGroup {
   const BlockRef* tick_map = nullptr; int tick_blocks = 0;
   const BlockRef* self_map = nullptr; int self_blocks = 0;
   double* prev_dev = nullptr;       // [neig] scratch of the convergence kernel
+  const int32_t* skip = nullptr;    // optional per-problem predicate (non-zero: the problem is dropped)
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
 };
@@ -109,7 +110,7 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
                                 int max_sweeps, bool debug, hipStream_t s, int* sweeps_out) {
   *sweeps_out = 0;
   if (g.neig == 0) return TADMM_OK;
-  launch_jacobi_init(g.ed, g.neig, s);
+  launch_jacobi_init(g.ed, g.neig, s, g.skip);
   HIP_OK(h, hipMemsetAsync(g.prev_dev, 0, (size_t)g.neig * 8, s));
   if (g.gsteps == 0) return TADMM_OK;      // every problem is a single block: nothing to rotate
   bool all_done = false;

@@ -40,8 +40,13 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 constexpr int kPair = 2 * kJB;  // 16
 constexpr int kHP = kPair + 2;  // padded leading dimension of the 16x16 LDS images (even: 16-byte aligned rows)
 
-__global__ __launch_bounds__(256) void jacobi_init_kernel(const EigDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void jacobi_init_kernel(const EigDesc* __restrict__ descs,
+                                                          const int32_t* __restrict__ skip) {
   const EigDesc d = descs[blockIdx.x];
+  if (skip && skip[blockIdx.x]) {           // dropped problem: finished before it starts
+    if (threadIdx.x == 0) *d.done = 1;
+    return;
+  }
   // scale reference: squared column norms of X = G are >= G_jj^2, so the largest diagonal entry squared
   // is a cheap lower bound of the largest squared column norm (= lambda_max^2 at convergence)
   __shared__ double red[4];
@@ -933,8 +938,10 @@ void dump_stamps() {}
 
 // ---- finalize: eigenvalues = column norms, descending order, scaled eigenvectors ----
 __global__ __launch_bounds__(256) void eig_norms_kernel(const EigDesc* __restrict__ descs,
-                                                        const BlockRef* __restrict__ map) {
+                                                        const BlockRef* __restrict__ map,
+                                                        const int32_t* __restrict__ skip) {
   const BlockRef br = map[blockIdx.x];
+  if (skip && skip[br.prob]) return;
   const EigDesc d = descs[br.prob];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = br.local * 4 + wave;
@@ -949,8 +956,10 @@ __global__ __launch_bounds__(256) void eig_norms_kernel(const EigDesc* __restric
   if (lane == 0) d.lam[j] = (j < d.N) ? sqrt(s) : -1.0;
 }
 
-__global__ __launch_bounds__(256) void eig_sort_kernel(const EigDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void eig_sort_kernel(const EigDesc* __restrict__ descs,
+                                                       const int32_t* __restrict__ skip) {
   extern __shared__ double slam[];
+  if (skip && skip[blockIdx.x]) return;
   const EigDesc d = descs[blockIdx.x];
   for (int j = threadIdx.x; j < d.Npad; j += 256) slam[j] = d.lam[j];
   __syncthreads();
@@ -967,8 +976,10 @@ __global__ __launch_bounds__(256) void eig_sort_kernel(const EigDesc* __restrict
 }
 
 __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restrict__ descs,
-                                                          const BlockRef* __restrict__ map) {
+                                                          const BlockRef* __restrict__ map,
+                                                          const int32_t* __restrict__ skip) {
   const BlockRef br = map[blockIdx.x];
+  if (skip && skip[br.prob]) return;
   const EigDesc d = descs[br.prob];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = br.local * 4 + wave;
@@ -993,7 +1004,7 @@ __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restr
   const double inv = (lam > 0.0) ? sgn / lam : 0.0;
   const double sig = sqrt(fmax(lam, 0.0));
   const double isig = (sig > 0.0) ? 1.0 / sig : 0.0;
-  const int r = d.r, N = d.N;
+  const int r = d.ldo ? d.ldo : d.r, N = d.N;
   for (int i = lane; i < N; i += 64) {
     const double v = row[i] * inv;
     if (d.mode == 0) {
@@ -1001,6 +1012,8 @@ __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restr
     } else if (d.mode == 1) {
       d.out_a[(int64_t)i * r + c] = (float)(v * isig);
       d.out_b[(int64_t)c * N + i] = (float)(v * sig);
+    } else if (d.mode == 3) {
+      d.out_a[(int64_t)i * r + c] = (float)(v * isig);
     }
     if (d.evec_out) d.evec_out[(int64_t)c * N + i] = v;
   }
@@ -1050,9 +1063,9 @@ void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double to
                      verdict_pinned);
 }
 
-void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s) {
+void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip) {
   if (nprob <= 0) return;
-  hipLaunchKernelGGL(jacobi_init_kernel, dim3(nprob), dim3(256), 0, s, descs_dev);
+  hipLaunchKernelGGL(jacobi_init_kernel, dim3(nprob), dim3(256), 0, s, descs_dev, skip);
 }
 
 size_t jacobi_tick_lds_bytes(int ld_max) { return ((size_t)kPair * (ld_max + 2) + kPairScratchDoubles) * 8; }
@@ -1120,17 +1133,19 @@ void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int n
     fprintf(stderr, "[tadmm] jacobi tick launch failed: %s (blocks=%d lds=%zu super=%d)\n", hipGetErrorString(e),
             nblocks, lds_bytes, (int)super);
 }
-void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                      const int32_t* skip) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(eig_norms_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  hipLaunchKernelGGL(eig_norms_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
-void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s) {
+void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip) {
   if (nprob <= 0) return;
-  hipLaunchKernelGGL(eig_sort_kernel, dim3(nprob), dim3(256), 16384, s, descs_dev);
+  hipLaunchKernelGGL(eig_sort_kernel, dim3(nprob), dim3(256), 16384, s, descs_dev, skip);
 }
-void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
+                        const int32_t* skip) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(eig_extract_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  hipLaunchKernelGGL(eig_extract_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
 
 }  // namespace tadmm

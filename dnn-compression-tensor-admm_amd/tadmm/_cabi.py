@@ -75,6 +75,15 @@ ABI = {
     "tadmm_plan_set_jacobi": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
     "tadmm_plan_ranks": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "tadmm_plan_destroy": (C.c_int, [C.c_void_p]),
+    "tadmm_tucker_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(LayerDesc), C.POINTER(C.c_size_t)]),
+    "tadmm_tucker_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(LayerDesc), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_void_p)]),
+    "tadmm_tucker_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tadmm_tucker_factors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p)]),
+    "tadmm_tucker_iterations": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p]),
+    "tadmm_tucker_destroy": (C.c_int, [C.c_void_p]),
     "tadmm_penalty_scratch_doubles": (C.c_int, []),
     "tadmm_penalty": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),

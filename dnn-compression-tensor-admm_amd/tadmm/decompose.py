@@ -84,9 +84,9 @@ def decompose_state_dict(dense: Dict[str, torch.Tensor], hp_dict, format: str, v
                             out[f"{p}in_tt_cores.{j - n_out - 1}"] = c
             plan.close()
     elif format == "tk":
-        for name in table:
-            w = dense[name].detach().to(device, torch.float32).contiguous()
-            core, (u_out, u_in), _ = tucker.partial_tucker(w, hp_dict.ranks[name])
+        ws = [dense[name].detach().to(device, torch.float32).contiguous() for name in table]
+        res = tucker._plan_decompose(ws, [hp_dict.ranks[name] for name in table]) if table else []
+        for name, w, (core, (u_out, u_in), _, _) in zip(table, ws, res):
             p = _prefix(name)
             first, last = u_in.t().contiguous().cpu(), u_out.contiguous().cpu()
             if w.dim() == 4 and variant == "C":

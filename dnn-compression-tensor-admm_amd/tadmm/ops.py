@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import _cabi
-from ._cabi import (FLAG_SKIP_ROTATIONS, KIND_SVD, KIND_TT_CONV, KIND_TT_LINEAR, GemmDesc, Handle, LayerDesc,
-                    TadmmError, make_layer_desc)
+from ._cabi import (FLAG_SKIP_ROTATIONS, KIND_SVD, KIND_TT_CONV, KIND_TT_LINEAR, KIND_TUCKER2, GemmDesc, Handle,
+                    LayerDesc, TadmmError, make_layer_desc)
 
 
 def _require_cuda(t: torch.Tensor, what: str):
@@ -152,6 +152,90 @@ def gemm_desc(A, B, Cout, M, N, K, a_strides, b_strides, c_strides, alpha=1.0, b
     g.bias_n = bias_n
     g.bias_m = bias_m
     return g
+
+
+class TuckerPlan:
+    """Grouped Tucker-2 projection of a set of layers (the 'tk' branches of ADMM.update, admm.py:47-50, :59-62).
+
+    layers: sequence of dicts with keys W, U, Z (float32 device tensors, 4-D (O,I,kh,kw) or 2-D (out,in)) and
+    ranks = [r_out, r_in].  HOSVD + HOOI for all layers in lock-step on the device (csrc/tucker_plan.hip).
+    """
+
+    def __init__(self, layers: Sequence[dict], n_iter_max: int = 100, tol: float = 1e-4):
+        if not layers:
+            raise ValueError("empty plan")
+        dev = layers[0]["W"].device
+        self.device = dev
+        self.h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        lib = self.h.lib
+        n = len(layers)
+        self.n = n
+        self._descs = (LayerDesc * n)()
+        self._keep = []
+        self._shapes = []
+        Wp = (C.c_void_p * n)()
+        Up = (C.c_void_p * n)()
+        Zp = (C.c_void_p * n)()
+        for i, L in enumerate(layers):
+            for key in ("W", "U", "Z"):
+                _require_cuda(L[key], key)
+                if L[key].shape != L["W"].shape:
+                    raise TadmmError(-1, f"{key} shape differs from W")
+            shape = list(L["W"].shape)
+            if len(shape) not in (2, 4):
+                raise TadmmError(-1, "Tucker layers are 2-D or 4-D")
+            self._descs[i] = make_layer_desc(KIND_TUCKER2, shape, None, L["ranks"], 0, n_iter_max, tol)
+            Wp[i], Up[i], Zp[i] = L["W"].data_ptr(), L["U"].data_ptr(), L["Z"].data_ptr()
+            self._keep.append((L["W"], L["U"], L["Z"]))
+            self._shapes.append((shape, int(L["ranks"][0]), int(L["ranks"][1])))
+        size = C.c_size_t()
+        self.h.check(lib.tadmm_tucker_workspace_bytes(self.h.ptr, n, self._descs, C.byref(size)))
+        self.workspace_bytes = int(size.value)
+        self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=dev)
+        self.resid_sq = torch.zeros(n, dtype=torch.float64, device=dev)
+        self._plan = C.c_void_p()
+        self.h.check(lib.tadmm_tucker_create(self.h.ptr, n, self._descs, Wp, Up, Zp, self.workspace.data_ptr(),
+                                             self.workspace_bytes, C.byref(self._plan)))
+
+    def run(self, update_u: bool = True, use_u: bool = True) -> torch.Tensor:
+        self.h.check(self.h.lib.tadmm_tucker_run(self._plan, int(update_u), int(use_u), self.resid_sq.data_ptr(),
+                                                 _stream(self.device)))
+        return self.resid_sq
+
+    def _view(self, ptr: int, numel: int) -> torch.Tensor:
+        off = ptr - self.workspace.data_ptr()
+        return self.workspace[off:off + 4 * numel].view(torch.float32)
+
+    def factors(self, layer: int):
+        """(core, U_out, U_in) of the last run as tensors shaped like tensorly's partial_tucker output:
+        core (r_out, r_in, kh, kw) | (r_out, r_in), U_out (O, r_out), U_in (I, r_in).  Copies."""
+        shape, ro, ri = self._shapes[layer]
+        c, a, b = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.h.check(self.h.lib.tadmm_tucker_factors(self._plan, layer, C.byref(c), C.byref(a), C.byref(b)))
+        k2 = shape[2] * shape[3] if len(shape) == 4 else 1
+        core = self._view(c.value, ro * k2 * ri).view(ro, k2, ri).permute(0, 2, 1).contiguous()
+        core = core.view(ro, ri, shape[2], shape[3]) if len(shape) == 4 else core.view(ro, ri)
+        u_out = self._view(a.value, shape[0] * ro).view(shape[0], ro).clone()
+        u_in = self._view(b.value, shape[1] * ri).view(shape[1], ri).clone()
+        return core, u_out, u_in
+
+    def iterations(self):
+        """(HOOI sweeps per layer, final relative reconstruction error per layer) of the last run."""
+        it = (C.c_int32 * self.n)()
+        err = (C.c_double * self.n)()
+        self.h.check(self.h.lib.tadmm_tucker_iterations(self._plan, it, err, _stream(self.device)))
+        return list(it), list(err)
+
+    def close(self):
+        if getattr(self, "_plan", None) is not None and self._plan:
+            self.h.lib.tadmm_tucker_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GemmBatch:

@@ -66,7 +66,35 @@ def _mode1_T(t: torch.Tensor, f: torch.Tensor) -> torch.Tensor:
 
 
 def partial_tucker(w: torch.Tensor, ranks: Sequence[int], n_iter_max: int = 100, tol: float = 1e-4):
-    """Tucker-2 over modes (0,1).  Returns core (r_out, r_in, ...), [U_out (O,r_out), U_in (I,r_in)], errors."""
+    """Tucker-2 over modes (0,1).  Returns core (r_out, r_in, ...), [U_out (O,r_out), U_in (I,r_in)], errors.
+
+    Runs on the batched device plan (csrc/tucker_plan.hip) with a single layer; `errors` holds the final relative
+    reconstruction error repeated once per HOOI sweep the layer ran (the per-sweep history stays on the device).
+    """
+    core, factors, errs, _ = _plan_decompose([w], [ranks], n_iter_max, tol)[0]
+    return core, factors, errs
+
+
+def _plan_decompose(ws, ranks_list, n_iter_max: int = 100, tol: float = 1e-4):
+    """HOSVD + HOOI of several weights in ONE grouped plan.  -> [(core, [U_out, U_in], errs, Z)]"""
+    layers = []
+    for w, r in zip(ws, ranks_list):
+        w = w.detach().float().contiguous()
+        layers.append(dict(W=w, U=torch.zeros_like(w), Z=torch.empty_like(w), ranks=[int(r[0]), int(r[1])]))
+    plan = ops.TuckerPlan(layers, n_iter_max=n_iter_max, tol=tol)
+    plan.run(update_u=False, use_u=False)
+    its, errs = plan.iterations()
+    out = []
+    for i, L in enumerate(layers):
+        core, u_out, u_in = plan.factors(i)
+        out.append((core, [u_out, u_in], [errs[i]] * max(1, its[i]), L["Z"]))
+    plan.close()
+    return out
+
+
+def partial_tucker_eager(w: torch.Tensor, ranks: Sequence[int], n_iter_max: int = 100, tol: float = 1e-4):
+    """The same algorithm driven step by step from Python on the Gram / eigh / GEMM primitives (one layer, one
+    host round trip per sweep).  Kept as an independent cross-check of the batched plan in the tests."""
     w = w.detach().float().contiguous()
     r_out, r_in = int(ranks[0]), int(ranks[1])
     factors = [_leading_left_vectors(_unfold0(w), r_out), _leading_left_vectors(_unfold1(w), r_in)]
@@ -94,8 +122,8 @@ def tucker_to_tensor(core: torch.Tensor, factors) -> torch.Tensor:
 
 
 def project(w: torch.Tensor, ranks) -> Tuple[torch.Tensor, List[float]]:
-    core, factors, errs = partial_tucker(w, ranks)
-    return tucker_to_tensor(core, factors).reshape(w.shape), errs
+    _, _, errs, z = _plan_decompose([w], [ranks])[0]
+    return z.reshape(w.shape), errs
 
 
 def project_numpy(z: np.ndarray, ranks, device) -> np.ndarray:
@@ -105,23 +133,20 @@ def project_numpy(z: np.ndarray, ranks, device) -> np.ndarray:
 
 
 class TuckerProjector:
-    """The 'tk' branch of ADMM.update for the layers named in `names` (admm.py:47-50, :59-62)."""
+    """The 'tk' branch of ADMM.update for the layers named in `names` (admm.py:47-50, :59-62): all of them in ONE
+    grouped device plan, W/U/Z captured by pointer."""
 
     def __init__(self, admm, names):
         self.admm = admm
         self.names = list(names)
+        a = admm
+        params = dict(a._named())
+        layers = [dict(W=params[n].data, U=a.u[n], Z=a.z[n], ranks=list(a.hp_dict.ranks[n])) for n in self.names]
+        self.plan = ops.TuckerPlan(layers)
 
     def run(self, update_u: bool) -> Dict[str, float]:
-        a = self.admm
-        params = dict(a._named())
-        resid = {}
-        for name in self.names:
-            w = params[name].data
-            zin = w + a.u[name]
-            z, _ = project(zin, a.hp_dict.ranks[name])
-            a.z[name].copy_(z)
-            if update_u:
-                diff = w - a.z[name]
-                a.u[name] += diff
-                resid[name] = float(torch.linalg.vector_norm(diff))
-        return resid
+        r = self.plan.run(update_u=update_u, use_u=True)
+        if not update_u:
+            return {}
+        vals = r.sqrt().cpu().tolist()
+        return {n: vals[i] for i, n in enumerate(self.names)}

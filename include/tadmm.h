@@ -101,7 +101,8 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
  *   update_u     : 0 -> only Z is written (ADMM.__init__ + update(update_u=False), engines.py:245)
  *   use_u        : 0 -> project W alone (the --decompose path: TTConv.py:96-109, TTLinear.py:61-66)
  *   resid_sq_dev : NULL or device double[n_layers]  <- ||W-Z||_2^2 per layer (admm.py:73-76)
- * The call synchronises the stream once per Jacobi sweep (convergence poll). */
+ * Convergence of the Jacobi sweeps is decided on the device; the host reads the verdict through pinned
+ * memory one sweep late, so the call blocks only at the end of each eigen-solve level. */
 int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream);
 /* Singular values kept at TT step `step` of layer `layer` in the last run (device->host copy,
  * synchronous).  out must hold ranks[step+1] doubles. */
@@ -117,6 +118,28 @@ int tadmm_plan_set_jacobi(tadmm_plan p, double tol, int inner_sweeps, int max_sw
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
 int tadmm_plan_destroy(tadmm_plan p);
+
+/* ---- Tucker-2 projection plan (admm.py:113-127: tensorly partial_tucker + tucker_to_tensor) ---- */
+/* All layers of kind TADMM_KIND_TUCKER2 (ranks[0] = r_out, ranks[1] = r_in; 4-D (O,I,kh,kw) or 2-D (out,in))
+ * are processed together: HOSVD initialisation, then HOOI sweeps until each layer meets tensorly's stopping
+ * rule (|err_it - err_{it-1}| < hooi_tol from the third sweep, at most hooi_max_iter sweeps; 0 selects the
+ * tensorly defaults 1e-4 / 100), then Z = core x_0 U_out x_1 U_in, U += W-Z and ||W-Z||^2 as in tadmm_plan_run.
+ * The stopping rule is evaluated on the device; layers that are finished drop out of the later grouped launches.
+ * PARITY UNPINNED: tensorly is not vendored by the reference. */
+typedef struct tadmm_tucker_plan_s* tadmm_tucker_plan;
+int tadmm_tucker_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, size_t* bytes);
+int tadmm_tucker_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
+                        float* const* U, float* const* Z, void* workspace, size_t workspace_bytes,
+                        tadmm_tucker_plan* out);
+int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream);
+/* Device pointers (inside the workspace, valid after a run) of a layer's factors:
+ * core (r_out, k2, r_in) row-major -- note the kernel-position axis in the middle --, U_out (O, r_out),
+ * U_in (I, r_in).  Columns beyond the number of singular values of an unfolding are zero. */
+int tadmm_tucker_factors(tadmm_tucker_plan p, int layer, const float** core, const float** u_out, const float** u_in);
+/* HOOI sweeps each layer ran in the last call and its final relative reconstruction error (host arrays of
+ * n_layers entries, either may be NULL); synchronises the stream. */
+int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double* errors_out_host, void* stream);
+int tadmm_tucker_destroy(tadmm_tucker_plan p);
 
 /* ---- augmented-Lagrangian penalty (admm.py:80-85) ---------------------- */
 /* loss_dev[0] += 0.5*rho*sum_i ||W_i - Z_i + U_i||^2 ; gradW[i] (nullable) = grad_scale*(W_i-Z_i+U_i)
