@@ -119,6 +119,7 @@ struct GemmDesc {
 constexpr int kGemmBM = 64, kGemmBN = 64;
 void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                  const int32_t* skip = nullptr);
+void launch_gemm_one(const GemmDesc& d, hipStream_t s);   // descriptor passed as a kernel argument
 
 // ---------------------------------------------------------------- penalty
 constexpr int kPenaltyBlocks = 1024;

@@ -67,15 +67,9 @@ __device__ __forceinline__ void store_tile4(float* __restrict__ S, int ldS, bool
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ descs,
-                                                   const BlockRef* __restrict__ map,
-                                                   const int32_t* __restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  const BlockRef br = map[blockIdx.x];
-  if (skip && skip[br.prob]) return;
-  const GemmDesc d = descs[br.prob];
-  const int tm = br.local / d.tiles_n, tn = br.local - tm * d.tiles_n;
+// one 64x64 output tile (`local` = tile index inside the problem)
+__device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* __restrict__ As, float* __restrict__ Bs) {
+  const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -120,6 +114,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ 
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ descs,
+                                                   const BlockRef* __restrict__ map,
+                                                   const int32_t* __restrict__ skip) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  const BlockRef br = map[blockIdx.x];
+  if (skip && skip[br.prob]) return;
+  const GemmDesc d = descs[br.prob];
+  gemm_tile(d, br.local, As, Bs);
+}
+
+// A single GEMM whose descriptor travels as a kernel argument: no descriptor upload, no block map
+// (the per-call path of the factorised layers' forward / backward products).
+__global__ __launch_bounds__(256) void gemm_one_kernel(const GemmDesc d) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  gemm_tile(d, blockIdx.x, As, Bs);
+}
+
+void launch_gemm_one(const GemmDesc& d, hipStream_t s) {
+  const int nblocks = d.tiles_m * d.tiles_n;
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(gemm_one_kernel, dim3(nblocks), dim3(256), 0, s, d);
 }
 
 void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, const int32_t* skip) {

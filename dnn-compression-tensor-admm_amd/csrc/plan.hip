@@ -842,6 +842,24 @@ int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, voi
   return TADMM_OK;
 }
 
+int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* sdesc, void* stream_) {
+  if (!h || !sdesc) return TADMM_ERR_INVALID;
+  const tadmm_gemm_desc& s = *sdesc;
+  if (s.M <= 0 || s.N <= 0 || s.K <= 0 || !s.A || !s.B || !s.C) CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_gemm: empty operand");
+  if (!((s.a_rs == 1) || (s.a_cs == 1)) || !((s.b_rs == 1) || (s.b_cs == 1)))
+    CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_gemm: each operand needs one unit stride");
+  GemmDesc g;
+  memset(&g, 0, sizeof g);
+  g.A = s.A; g.B = s.B; g.C = s.C; g.M = s.M; g.N = s.N; g.K = s.K;
+  g.a_rs = s.a_rs; g.a_cs = s.a_cs; g.b_rs = s.b_rs; g.b_cs = s.b_cs; g.c_rs = s.c_rs; g.c_cs = s.c_cs;
+  g.alpha = s.alpha; g.beta = s.beta; g.bias_n = s.bias_n; g.bias_m = s.bias_m;
+  g.tiles_m = (s.M + kGemmBM - 1) / kGemmBM;
+  g.tiles_n = (s.N + kGemmBN - 1) / kGemmBN;
+  launch_gemm_one(g, (hipStream_t)stream_);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
 // ---- standalone Gram / eigh (tests, Tucker path) ----
 static void gram_geom(int m, int n, StepGeom& st) {
   st.m = m; st.cols = n; st.trans = m > n;

@@ -169,6 +169,9 @@ typedef struct {
 size_t tadmm_gemm_pack_bytes(int n, const tadmm_gemm_desc* descs);
 int tadmm_gemm_pack(int n, const tadmm_gemm_desc* descs, void* blob_host, size_t blob_bytes, int* nblocks_out);
 int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, void* stream);
+/* One GEMM, descriptor passed by value to the kernel (no upload): the per-call path of the layers' forward and
+ * backward products (TTLinear.py:79-86, TTConv.py:133-147, TKConv.py:210-214, TKLinear.py:66-71). */
+int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* desc, void* stream);
 
 /* G = A A^T (m<=n) or A^T A (m>n) of a row-major float32 m x n matrix, exact fp32 products
  * accumulated in fp64 on v_mfma_f64_16x16x4_f64.  G is written as double[Npad][ldg] (zero padded; see tadmm_gram_ld), N=min(m,n).
