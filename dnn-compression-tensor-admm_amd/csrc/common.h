@@ -101,6 +101,11 @@ void launch_jacobi_cross(const EigDesc* descs_dev, const BlockRef* map_dev, int 
                          int ld_max, hipStream_t s);
 void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, int ld_max, hipStream_t s);
+// whole eigen-solve of small problems (Npad <= 64) in one launch, one workgroup per problem; converged flags go to
+// verdict_pinned[1 + p]
+bool jacobi_small_fits(int npad_max);
+void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, double tol, int max_sweeps,
+                         const int32_t* skip, int* verdict_pinned, hipStream_t s);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                       const int32_t* skip = nullptr);
 void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr);

@@ -95,6 +95,7 @@ struct EigGroup {
   const BlockRef* self_map = nullptr; int self_blocks = 0;
   double* prev_dev = nullptr;       // [neig] scratch of the convergence kernel
   const int32_t* skip = nullptr;    // optional per-problem predicate (non-zero: the problem is dropped)
+  int npad_max = 0;                 // largest padded problem size (<= 64: single-launch solver)
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
 };
@@ -106,10 +107,22 @@ struct EigGroup {
 // copy in the stream) is consumed after sweep g+1 has been queued, so the GPU never idles on a poll; the price
 // is one sweep of empty launches at the end.  The per-problem flags let the host stop launching the self pass
 // for small problems that are long finished.
+// Small groups (every problem <= 64 columns) run in ONE launch (jacobi_small_kernel decides convergence itself);
+// *small_pending is set and the caller, after queueing the group's finalize launches, calls check_small_group.
 static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll, double tol, int inner_sweeps,
-                                int max_sweeps, bool debug, hipStream_t s, int* sweeps_out) {
+                                int max_sweeps, bool debug, hipStream_t s, int* sweeps_out, bool* small_pending) {
   *sweeps_out = 0;
+  *small_pending = false;
   if (g.neig == 0) return TADMM_OK;
+  {
+    const char* e = getenv("TADMM_JACOBI_SMALL");     // 0: always use the tick kernels (A/B measurements)
+    if (g.npad_max > 0 && jacobi_small_fits(g.npad_max) && !(e && !atoi(e))) {
+      launch_jacobi_small(g.ed, g.neig, g.npad_max, tol, std::max(max_sweeps, 60), g.skip, poll.host, s);
+      HIP_OK(h, hipEventRecord(poll.ev[0], s));
+      *small_pending = true;
+      return TADMM_OK;
+    }
+  }
   launch_jacobi_init(g.ed, g.neig, s, g.skip);
   HIP_OK(h, hipMemsetAsync(g.prev_dev, 0, (size_t)g.neig * 8, s));
   if (g.gsteps == 0) return TADMM_OK;      // every problem is a single block: nothing to rotate
@@ -172,6 +185,14 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
   }
   if (!all_done) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in %d sweeps", max_sweeps);
   *sweeps_out = needed;
+  return TADMM_OK;
+}
+
+// The single-launch solver reports per-problem convergence through pinned memory: fail loudly if one hit the cap.
+static inline int check_small_group(tadmm_handle h, const EigGroup& g, PollCtx& poll) {
+  if (hipEventSynchronize(poll.ev[0]) != hipSuccess) CTX_FAIL(h, TADMM_ERR_HIP, "poll event failed");
+  for (int q = 0; q < g.neig; ++q)
+    if (!poll.host[1 + q]) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi (small problems) did not converge, problem %d", q);
   return TADMM_OK;
 }
 

@@ -919,6 +919,125 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   STAMP(20);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small problems (Npad <= 64, i.e. at most 8 blocks of 8 columns): the WHOLE eigen-solve in one launch.
+// One 4-wave workgroup per problem keeps all columns in LDS; a round of the tournament has at most four
+// block pairs, one per wave (Gram tile, 16x16 inner solve, column update -- no cross-wave traffic inside a
+// round, one barrier between rounds), and the convergence rule of `jacobi_conv_kernel` is evaluated by the
+// workgroup itself, so there is no host poll and no kernel boundary per round.  Used for the first / last TT
+// steps (N <= 32 on the ResNet tables) and for every eigen-problem of the CIFAR Tucker tables.
+// verdict: pinned host ints, [1 + p] = problem p converged.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallNpad = 64;
+constexpr int kSmallWaveScratch = 2 * kPair * kHP;     // H and Q of one wave
+
+__global__ __launch_bounds__(256) void jacobi_small_kernel(const EigDesc* __restrict__ descs,
+                                                           const int32_t* __restrict__ skip, double tol,
+                                                           int max_sweeps, int* __restrict__ verdict) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int p = blockIdx.x;
+  const EigDesc d = descs[p];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (skip && skip[p]) {
+    if (tid == 0) { *d.done = 1; verdict[1 + p] = 1; }
+    return;
+  }
+  const int Npad = d.Npad, ld = d.ld, ldp = Npad + 2, nb = d.nb;
+  const int pairs = nb >> 1, steps = nb - 1;
+  double* Xs = smem;                                                   // [Npad][ldp], row j = column j of X
+  double* wbase = Xs + Npad * ldp + wave * kSmallWaveScratch;
+  double (*Hs)[kHP] = reinterpret_cast<double (*)[kHP]>(wbase);
+  double (*Qs)[kHP] = Hs + kPair;
+  double* red = Xs + Npad * ldp + 4 * kSmallWaveScratch;               // [8]
+  int* flags = reinterpret_cast<int*>(red + 8);                        // [4]
+  double* __restrict__ XT = d.XT;
+  {
+    const int c2n = Npad >> 1;
+    for (int idx = tid; idx < Npad * c2n; idx += 256) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      *reinterpret_cast<double2_t*>(Xs + row * ldp + 2 * c2) =
+          *reinterpret_cast<const double2_t*>(XT + (int64_t)row * ld + 2 * c2);
+    }
+  }
+  __syncthreads();
+  // scale reference, as jacobi_init_kernel: (largest diagonal entry of G)^2 bounds the largest squared column norm
+  {
+    float g = 0.0f;
+    for (int j = tid; j < d.N; j += 256) g = fmaxf(g, fabsf((float)Xs[j * ldp + j]));
+    g = wave_max_f32(g);
+    if (lane == 0) red[wave] = (double)g;
+  }
+  __syncthreads();
+  const double g0 = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  const double hmax = g0 * g0;
+  __syncthreads();
+  const int r = lane & 15, q = lane >> 4;
+  double prev_m = 0.0, m = 1.0;
+  bool conv = false;
+  int sweep = 0;
+  for (; sweep < max_sweeps && !conv; ++sweep) {
+    double mx_sweep = 0.0;
+    for (int step = 0; step < steps; ++step) {
+      if (wave < pairs) {
+        int a, b;
+        rr_pair(nb, step, wave, a, b);
+        const double* row = Xs + sub_index(a, b, r) * ldp;
+        double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        for (int i = 0; i < Npad; i += 8) {
+          const double2_t v = *reinterpret_cast<const double2_t*>(row + i + 2 * q);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Hs[q + 4 * e][r] = acc0[e] + acc1[e];
+          Qs[q + 4 * e][r] = (q + 4 * e == r) ? 1.0 : 0.0;
+        }
+        wave_lds_fence();
+        PairScratch S;
+        S.H = Hs; S.Q = Qs; S.rotated = flags + wave;
+        mx_sweep = fmax(mx_sweep, pair_inner_solve_fast<true, true>(S, lane, hmax, tol, step == 0));
+        wave_lds_fence();
+        if (flags[wave]) apply_q_tiles(Xs, ldp, Npad, Qs, a, b, 0, 1, lane);
+      }
+      __syncthreads();
+    }
+    if (lane == 0) red[wave] = mx_sweep;
+    __syncthreads();
+    m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    conv = m < tol;
+    if (!conv && prev_m > 0.0 && prev_m < 1e-1 && m < 1e-3) {          // quadratic phase: see jacobi_conv_kernel
+      const double C = 10.0 * fmax(1.0, m / (prev_m * prev_m));
+      conv = C * m * m < 10.0 * tol;
+    }
+    prev_m = m;
+    __syncthreads();
+  }
+  {
+    const int c2n = Npad >> 1;
+    for (int idx = tid; idx < Npad * c2n; idx += 256) {
+      const int row = idx / c2n, c2 = idx - row * c2n;
+      *reinterpret_cast<double2_t*>(XT + (int64_t)row * ld + 2 * c2) =
+          *reinterpret_cast<const double2_t*>(Xs + row * ldp + 2 * c2);
+    }
+  }
+  if (tid == 0) {
+    *d.done = conv ? 1 : 0;
+    d.off[0] = m; d.off[1] = (double)sweep; d.off[2] = hmax;
+    verdict[1 + p] = conv ? 1 : 0;
+  }
+}
+
+bool jacobi_small_fits(int npad_max) { return npad_max <= kSmallNpad; }
+
+void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, double tol, int max_sweeps,
+                         const int32_t* skip, int* verdict_pinned, hipStream_t s) {
+  if (nprob <= 0) return;
+  const size_t lds = ((size_t)npad_max * (npad_max + 2) + 4 * kSmallWaveScratch + 8 + 4) * 8;
+  hipLaunchKernelGGL(jacobi_small_kernel, dim3(nprob), dim3(256), lds, s, descs_dev, skip, tol, max_sweeps,
+                     verdict_pinned);
+}
+
 #ifdef TADMM_STAMPS
 void dump_stamps() {
   unsigned long long h[32];

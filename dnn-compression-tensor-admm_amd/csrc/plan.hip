@@ -144,6 +144,7 @@ struct StepPlan {
   int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 2: register/LDS cross kernel + self
   Phase eig_self;                 // mode 2: block map of the once-per-sweep self kernel (nb/2 workgroups per problem)
   int ld_max = 0;
+  int npad_max = 0;
   size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
   size_t prev_off_dev = 0, alldone_off = 0;   // [neig] doubles of the convergence kernel / its verdict (int)
   std::vector<int> nb;            // per problem
@@ -411,6 +412,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       ed.push_back(e);
       sp.nb.push_back(st.nb);
       sp.ld_max = std::max(sp.ld_max, st.ld);
+      sp.npad_max = std::max(sp.npad_max, st.Npad);
       for (int b = 0; b < (st.Npad + 3) / 4; ++b) m_norm.push_back(BlockRef{p, b});
       for (int b = 0; b < (st.r + 3) / 4; ++b) m_ext.push_back(BlockRef{p, b});
       // projection GEMM
@@ -723,9 +725,12 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     eg.self_map = (const BlockRef*)D(sp.eig_self.map_off); eg.self_blocks = sp.eig_self.nblocks;
     eg.prev_dev = (double*)D(sp.prev_off_dev);
     eg.off_dev = (const double*)D(sp.off_off); eg.done_dev = (const int*)D(sp.done_off);
+    eg.npad_max = sp.npad_max;
     int gs = 0;
+    bool small_pending = false;
     {
-      const int rc = run_eig_group(h, eg, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &gs);
+      const int rc = run_eig_group(h, eg, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &gs,
+                                   &small_pending);
       if (rc != TADMM_OK) return rc;
     }
     sp.last_sweeps = gs;
@@ -737,6 +742,10 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     tic(0);
     launch_gemm((const GemmDesc*)D(sp.proj.desc_off), (const BlockRef*)D(sp.proj.map_off), sp.proj.nblocks, s);
     toc(0, 3);
+    if (small_pending) {      // the finalize + projection launches above are already queued behind it
+      const int rc = check_small_group(h, eg, p->poll);
+      if (rc != TADMM_OK) return rc;
+    }
   }
   tic(0);
   for (Phase& ph : p->recon)

@@ -69,7 +69,7 @@ struct Lsv {     // one grouped "leading singular vectors" phase over all layers
   Group gram_p, gram_r, tick, self, norm, ext, xg;
   size_t eig_desc_off = 0;
   std::vector<int> players;
-  int gsteps = 0, mode = 0, ld_max = 0;
+  int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0;
   size_t tick_lds = 0;
 };
 
@@ -271,7 +271,11 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     std::vector<int> gp_cost(n);
     v.players.assign(n, 0);
     v.ld_max = 0;
-    for (int l = 0; l < n; ++l) v.ld_max = std::max(v.ld_max, og[k * n + l].ld);
+    v.npad_max = 0;
+    for (int l = 0; l < n; ++l) {
+      v.ld_max = std::max(v.ld_max, og[k * n + l].ld);
+      v.npad_max = std::max(v.npad_max, og[k * n + l].Npad);
+    }
     v.mode = choose_jacobi_mode(v.ld_max);
     v.tick_lds = v.mode == 1 ? jacobi_tick2_lds_bytes(v.ld_max) : jacobi_tick_lds_bytes(v.ld_max);
     v.gsteps = 0;
@@ -476,15 +480,17 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     eg.prev_dev = (double*)D(p->prev_off);
     eg.off_dev = (const double*)D(p->off_off); eg.done_dev = (const int*)D(p->done_off);
     eg.skip = sk;
+    eg.npad_max = v.npad_max;
     int gs = 0;
-    const int rc = run_eig_group(h, eg, p->poll, p->jtol, p->inner, p->max_sweeps, p->debug, s, &gs);
+    bool small_pending = false;
+    const int rc = run_eig_group(h, eg, p->poll, p->jtol, p->inner, p->max_sweeps, p->debug, s, &gs, &small_pending);
     if (rc != TADMM_OK) return rc;
     jac_sweeps += gs;
     launch_eig_norms(ed, (const BlockRef*)D(v.norm.map_off), v.norm.nblocks, s, sk);
     launch_eig_sort(ed, n, s, sk);
     launch_eig_extract(ed, (const BlockRef*)D(v.ext.map_off), v.ext.nblocks, s, sk);
     launch_gemm((const GemmDesc*)D(v.xg.desc_off), (const BlockRef*)D(v.xg.map_off), v.xg.nblocks, s, sk);
-    return TADMM_OK;
+    return small_pending ? check_small_group(h, eg, p->poll) : TADMM_OK;
   };
   auto gemm = [&](int k, const int32_t* sk) {
     launch_gemm((const GemmDesc*)D(p->gemm[k].desc_off), (const BlockRef*)D(p->gemm[k].map_off), p->gemm[k].nblocks, s, sk);

@@ -82,3 +82,46 @@ def test_eigh_jacobi(dev, N, kind):
     R = G @ V.T - V.T * ev[:k]
     assert np.abs(R).max() <= 1e-10 * ref[0]
     assert sweeps <= 30, sweeps
+
+
+@pytest.mark.gpu
+def test_gram_direct_write_path_large_n(dev):
+    """N >= 704 gives >= 256 tile pairs, so the standalone Gram takes the no-split-K path: the product kernel
+    writes the tile, its mirror and the zero padding itself (no reduce pass)."""
+    from tadmm import ops
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(720, 900, generator=g)
+    G = ops.gram(a.to(dev)).cpu().numpy()
+    ref = a.double().numpy() @ a.double().numpy().T
+    assert G.shape == (720, 720)
+    np.testing.assert_allclose(G, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    np.testing.assert_array_equal(G, G.T)
+
+
+@pytest.mark.gpu
+def test_tucker_plan_is_deterministic_and_batches_mixed_layers(dev):
+    """One grouped Tucker plan over a conv, a 1x1 conv and two linear layers (one with more rows than columns,
+    one with r_out > r_in so a factor carries a zero column): run twice -> bitwise identical Z, U, residuals."""
+    from tadmm import ops
+    g = torch.Generator().manual_seed(4)
+    shapes = [(24, 16, 3, 3), (32, 48, 1, 1), (40, 12), (20, 14)]
+    ranks = [[10, 8], [12, 20], [6, 5], [5, 4]]
+    outs = []
+    for _ in range(2):
+        layers = []
+        gg = torch.Generator().manual_seed(4)
+        for s, r in zip(shapes, ranks):
+            w = (torch.randn(*s, generator=gg) * 0.2).to(dev)
+            layers.append(dict(W=w, U=torch.zeros_like(w), Z=torch.empty_like(w), ranks=r))
+        plan = ops.TuckerPlan(layers)
+        r1 = plan.run(update_u=True).clone()
+        r2 = plan.run(update_u=True).clone()
+        its, errs = plan.iterations()
+        assert all(i >= 3 for i in its) and all(np.isfinite(e) for e in errs)
+        outs.append(([L["Z"].clone() for L in layers], [L["U"].clone() for L in layers], r1, r2))
+        plan.close()
+    for za, zb in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(za, zb)
+    for ua, ub in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(ua, ub)
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
