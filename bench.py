@@ -267,6 +267,9 @@ def main():
             "hbm_sweeps": {"achieved_gbs": my_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0,
                            "peak_gbs": PEAK_HBM_GBS, "algorithmic_bytes": my_bytes},
             "eig_time_share": ph["eig_ms"] / max(1e-9, sum(v for k, v in ph.items() if k.endswith("_ms"))),
+            # the eigen-solve against the fp64 matrix peak, with the implementation-independent 8*N^3 model
+            "eig_f64": {"algorithmic_tflops": sum(flops[i]["eig"] for i in mine) / (ph["eig_ms"] * 1e-3) / 1e12
+                        if ph["eig_ms"] > 0 else 0.0, "peak_tflops": PEAK_F64_MFMA_TFLOPS},
         }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.config)
