@@ -94,11 +94,9 @@ bool jacobi_tick3_fits(int ld_max);
 // round-1 update).  Needs launch_jacobi_self on the first tick of every sweep (it refreshes EigDesc::sblk).
 void launch_jacobi_tick3(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                          int ld_max, hipStream_t s);
-// register/LDS-resident cross phase (jacobi_cross.hip) + its once-per-sweep companion (tick1 in self mode)
-size_t jacobi_cross_lds_bytes(int ld_max);
-int jacobi_cross_max_ld();
-void launch_jacobi_cross(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
-                         int ld_max, hipStream_t s);
+// row lengths up to this are padded to whole 1 KiB chunks (128 doubles), longer ones to 32 doubles
+constexpr int kLd128Max = 1152;
+// once-per-sweep companion of tick3 (tick1 in self mode): within-block pairs + refresh of the carried self-Grams
 void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, int ld_max, hipStream_t s);
 // whole eigen-solve of small problems (Npad <= 64) in one launch, one workgroup per problem; converged flags go to

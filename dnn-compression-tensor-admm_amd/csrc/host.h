@@ -50,13 +50,13 @@ static inline void xcd_group(std::vector<BlockRef>& m) {
 }
 
 // Which Jacobi kernel a group of problems whose longest row is ld_max uses:
-// 3 = tick3 (carried self-Grams) + self pass, 2 = experimental cross kernel + self pass, 1 = LDS super-pair,
-// 0 = plain pair kernel.  TADMM_JACOBI_MODE overrides the preference, never the capacity checks.
+// 3 = tick3 (carried self-Grams) + self pass, 1 = LDS super-pair, 0 = plain pair kernel.
+// TADMM_JACOBI_MODE (0 | 1 | 3) overrides the preference, never the capacity checks.
 static inline int choose_jacobi_mode(int ld_max) {
   const char* em = getenv("TADMM_JACOBI_MODE");
   int want = em ? atoi(em) : 3;
+  if (want != 0 && want != 1) want = 3;
   if (want == 3 && (!jacobi_tick3_fits(ld_max) || ld_max % 64)) want = 1;
-  if (want == 2 && (ld_max > jacobi_cross_max_ld() || ld_max % 128)) want = 1;
   if (want == 1 && !jacobi_tick2_fits(ld_max)) want = 0;
   return want;
 }
@@ -147,8 +147,7 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
         for (int q = 0; q < g.neig && !any_first; ++q)
           any_first = !known_done[q] && g.players[q] > 1 && (tick % (g.players[q] - 1)) == 0;
         if (any_first) launch_jacobi_self(g.ed, g.self_map, g.self_blocks, tick, tol, inner_sweeps, g.ld_max, s);
-        if (g.mode == 3) launch_jacobi_tick3(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
-        else launch_jacobi_cross(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
+        launch_jacobi_tick3(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
       } else {
         launch_jacobi_tick(g.ed, g.tick_map, g.tick_blocks, tick, tol, inner_sweeps, g.tick_lds, g.mode == 1, s);
       }

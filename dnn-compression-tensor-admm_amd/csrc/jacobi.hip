@@ -13,13 +13,15 @@
 //   3. Xp <- Xp * Q                                                              -- v_mfma_f64_16x16x4
 // X is stored transposed (XT[j][:] = column j, contiguous) so every access is a row segment.
 //
-// Two launch shapes ("ticks"), both following a round-robin tournament so that after a sweep every pair
-// of blocks has met exactly once; the kernel boundary is the only global synchronisation:
-//   tick2 (ld <= 512): a workgroup owns a *super-pair* of two 16-column super-blocks (32 columns, 128 KiB
-//          of LDS), loads it once, runs the 2 rounds of 2 concurrent sub-pair visits (4 waves each) that
-//          cover its 4 cross sub-pairs entirely in LDS, and stores it once -- half the launches and half
-//          the HBM/Infinity-Cache traffic of tick1 per sweep;
-//   tick1 (any ld):   a workgroup owns one pair (16 columns).
+// Launch shapes ("ticks"), all following a round-robin tournament so that after a sweep every pair of blocks
+// has met exactly once; the kernel boundary is the only global synchronisation:
+//   tick3 (default, ld <= 512): a workgroup owns a *super-pair* of two 16-column super-blocks (32 columns in LDS),
+//          carries the two self-Grams from launch to launch, computes ONE cross-Gram tile, and runs 2 rounds of
+//          2 concurrent 16x16 sub-problems (see the header of jacobi_tick3_kernel); the within-super-block
+//          pairs are rotated once per sweep by tick1 in "self mode", which also refreshes the carried Grams;
+//   tick2 (fallback, ld <= ~590): the same super-pair shape, every Gram recomputed from the columns;
+//   tick1 (any ld that fits 16 columns in LDS): a workgroup owns one pair (16 columns);
+//   small (Npad <= 64): the whole eigen-solve in one launch, one workgroup per problem (jacobi_small_kernel).
 // Index pairs inside a block (tick1) / inside a super-block (tick2) are rotated on the first tick of a
 // sweep only, when every (super-)block is in exactly one pair.
 //
@@ -27,8 +29,8 @@
 // w_ij = max(1, 1e-14/tol * lambda_max/min(lambda_i, lambda_j)): columns with small eigenvalues carry fp64
 // rounding noise of relative size ~eps*lambda_max/lambda and cannot be orthogonalised beyond it, so their
 // target scales accordingly (exactly low-rank inputs would otherwise never terminate).  A problem is
-// converged when a whole sweep saw nothing above `tol`; Jacobi converges quadratically, so tol = 1e-9
-// leaves ~1e-16 after that sweep.
+// converged when a whole sweep saw nothing above `tol` (Jacobi converges quadratically, so tol = 1e-9 leaves
+// ~1e-16 after that sweep) or when the quadratic-phase prediction of jacobi_conv_kernel says so.
 #include "common.h"
 #include <cstdio>
 
@@ -418,7 +420,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
 __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restrict__ descs,
                                                           const BlockRef* __restrict__ map, int tick, double tol,
                                                           int inner_sweeps, int self_mode) {
-  // self_mode: companion of jacobi_cross_kernel.  The tournament runs over nb/2 super-blocks of 16
+  // self_mode: companion of jacobi_tick3_kernel.  The tournament runs over nb/2 super-blocks of 16
   // columns; this kernel acts only on the first tick of a sweep, one workgroup per super-block, and
   // rotates all 120 index pairs inside it (blocks 2*local and 2*local+1, `within` rotations included).
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   }
   __syncthreads();
   // every thread has taken its convergence decision by now: safe to clear the slot of the NEXT sweep
-  // (in self mode the cross kernel of the same tick does it)
+  // (in self mode the tick3 launch of the same tick does it)
   if (!self_mode && step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
 
   const int per = ld >> 2;                         // ld is a multiple of 32 -> per % 8 == 0

@@ -103,8 +103,8 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     st.skip = (d.flags & TADMM_FLAG_SKIP_ROTATIONS) && !st.trans && st.r == st.m;
     st.Npad = (int)align_up(st.N, 4 * kJB);     // whole super-pairs of 2 x 16 columns
     st.nb = st.Npad / kJB;
-    // row length of the eigen-solver's X image: 1 KiB chunks for the register-resident cross kernel
-    st.ld = (int)align_up(st.N, st.N <= jacobi_cross_max_ld() ? 128 : 32);
+    // row length of the eigen-solver's X image: whole 1 KiB chunks (tick3 wants ld % 64 == 0)
+    st.ld = (int)align_up(st.N, st.N <= kLd128Max ? 128 : 32);
     st.nt = (st.N + 31) / 32;
     if (!st.skip && jacobi_tick_lds_bytes(st.ld) > 160 * 1024)
       CTX_FAIL(h, TADMM_ERR_UNSUPPORTED,
@@ -141,7 +141,7 @@ struct StepPlan {
   size_t tick_lds = 0;            // dynamic LDS of the tick launches of this step
   int last_sweeps = 0;            // global sweeps the previous run needed (polls start 2 sweeps before that)
   bool super = false;             // LDS-resident super-pair kernel (all problems of the level fit)
-  int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 2: register/LDS cross kernel + self
+  int mode = 0;                   // 0: pairs (tick1), 1: LDS super-pairs (tick2), 3: tick3 + self pass
   Phase eig_self;                 // mode 2: block map of the once-per-sweep self kernel (nb/2 workgroups per problem)
   int ld_max = 0;
   int npad_max = 0;
@@ -875,7 +875,7 @@ static void gram_geom(int m, int n, StepGeom& st) {
   st.N = std::min(m, n);
   st.Npad = (int)align_up(st.N, 4 * kJB);
   st.nb = st.Npad / kJB;
-  st.ld = (int)align_up(st.N, st.N <= jacobi_cross_max_ld() ? 128 : 32);
+  st.ld = (int)align_up(st.N, st.N <= kLd128Max ? 128 : 32);
   st.nt = (st.N + 31) / 32;
   const int64_t K = st.trans ? m : n;
   const int ntp = st.nt * (st.nt + 1) / 2;
@@ -938,7 +938,7 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
 }
 
 size_t tadmm_eigh_scratch_bytes(int N) {
-  const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, N <= jacobi_cross_max_ld() ? 128 : 32);
+  const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, N <= kLd128Max ? 128 : 32);
   return align_up(Npad * ld * 8, 256) + align_up(sizeof(EigDesc), 256) + 4 * align_up(Npad * sizeof(BlockRef), 256) +
          align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024 + align_up((Npad / 16) * 256 * 8, 256);
 }
@@ -948,11 +948,10 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   if (!h || !G || !evals_out || !evecs_out || !scratch || N <= 0) return TADMM_ERR_INVALID;
   if (scratch_bytes < tadmm_eigh_scratch_bytes(N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "eigh scratch too small");
   hipStream_t s = (hipStream_t)stream_;
-  const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, N <= jacobi_cross_max_ld() ? 128 : 32),
+  const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, N <= kLd128Max ? 128 : 32),
             nb = Npad / kJB;
   int mode = getenv("TADMM_JACOBI_MODE") ? atoi(getenv("TADMM_JACOBI_MODE")) : 3;
   if (mode == 3 && (!jacobi_tick3_fits(ld) || ld % 64)) mode = 1;
-  if (mode == 2 && (ld > jacobi_cross_max_ld() || ld % 128)) mode = 1;
   if (mode == 1 && !jacobi_tick2_fits(ld)) mode = 0;
   const bool super = mode >= 1;
   const int units = super ? nb / 2 : nb;
@@ -1000,8 +999,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
     for (int t = 0; t < units - 1; ++t, ++tick) {
       if (mode >= 2) {
         if (t == 0) launch_jacobi_self(edev, m_self, units, tick, tol, 1, ld, s);
-        if (mode == 3) launch_jacobi_tick3(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
-        else launch_jacobi_cross(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
+        launch_jacobi_tick3(edev, m_tick, (int)vt.size(), tick, tol, ld, s);
       } else {
         launch_jacobi_tick(edev, m_tick, (int)vt.size(), tick, tol, 1, tick_lds, mode == 1, s);
       }
