@@ -135,7 +135,7 @@ struct tadmm_tucker_plan_s {
   Lsv lsv[4];            // 0: init U_out, 1: init U_in, 2: HOOI U_out, 3: HOOI U_in
   Group gemm[5];         // 0: P = T x1 U_in, 1: P = T x0 U_out, 2: C, 3: Z' = C x1 U_in, 4: Zmat = Z' x0 U_out
   Group unfold, fold;
-  size_t sweep_desc_off = 0, resid_partial_off = 0;
+  size_t sweep_desc_off = 0, resid_partial_off = 0, fac_begin = 0, fac_end = 0;
   size_t off_off = 0, done_off = 0, prev_off = 0, skip_off = 0, nT_off = 0, nC_off = 0, err_off = 0, iters_off = 0,
          tol_off = 0, ptrT_off = 0, ptrC_off = 0, numT_off = 0, numC_off = 0;
   PollCtx poll;          // Jacobi verdicts
@@ -168,6 +168,14 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
   };
 
   // ---- per-layer data buffers ----
+  // the factors of all layers sit back to back so that one memset clears them at the start of a run
+  P->fac_begin = ar.take(0);
+  for (int l = 0; l < n; ++l) {
+    TLayer& t = P->L[l];
+    t.Uo = ar.take((size_t)t.O * t.ro * 4);
+    t.Ui = ar.take((size_t)t.I * t.ri * 4);
+  }
+  P->fac_end = ar.off;
   std::vector<OpGeom> og(4 * n);
   for (int l = 0; l < n; ++l) {
     TLayer& t = P->L[l];
@@ -189,8 +197,6 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     t.T = ar.take((size_t)t.numel * 4);
     t.P = ar.take((size_t)std::max((int64_t)t.O * t.K2 * t.ri, (int64_t)t.ro * t.K2 * t.I) * 4);
     t.C = ar.take((size_t)t.ro * t.K2 * t.ri * 4);
-    t.Uo = ar.take((size_t)t.O * t.ro * 4);
-    t.Ui = ar.take((size_t)t.I * t.ri * 4);
     t.Vs = ar.take(vsb);
     t.XT = ar.take(xtb);
     t.gpart = ar.take(gpb);
@@ -500,10 +506,7 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
   HIP_OK(h, hipMemsetAsync(D(p->err_off), 0, (size_t)n * 16, s));
   HIP_OK(h, hipMemsetAsync(D(p->iters_off), 0, (size_t)n * 4, s));
   // factors carry zero columns beyond the number of singular values of their unfolding (never written)
-  for (const TLayer& t : p->L) {
-    HIP_OK(h, hipMemsetAsync(D(t.Uo), 0, (size_t)t.O * t.ro * 4, s));
-    HIP_OK(h, hipMemsetAsync(D(t.Ui), 0, (size_t)t.I * t.ri * 4, s));
-  }
+  HIP_OK(h, hipMemsetAsync(D(p->fac_begin), 0, p->fac_end - p->fac_begin, s));
   launch_unfold((const SweepDesc*)D(p->sweep_desc_off), (const BlockRef*)D(p->unfold.map_off), p->unfold.nblocks, use_u, s);
   hipLaunchKernelGGL(sumsq_kernel, dim3(n), dim3(256), 0, s, (const float* const*)D(p->ptrT_off),
                      (const int64_t*)D(p->numT_off), (double*)D(p->nT_off), (const int32_t*)nullptr);
