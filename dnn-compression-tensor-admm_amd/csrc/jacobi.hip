@@ -312,7 +312,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
     const int g8 = lane >> 3, l8 = lane & 7;
     const double scale2 = inv_hmax;                       // entries of H_cur are ~lambda^2 <= hmax
     // rotation of rows (p,q) given the three entries a = h_pp, b = h_qq, g = h_pq of the current matrix
-    auto rotation = [&](double a, double b, double g, double& c, double& s) -> bool {
+    auto rotation = [&](double a, double b, double g, double& c, double& s, double& t) -> bool {
       if (!(g * g > 1e-36 * fabs(a * b) && fabs(g) > 1e-300)) return false;   // uniform inside the 8-lane group
       const float zf = (float)((b - a) * scale2), wf = (float)(2.0 * g * scale2);
       const float az = fabsf(zf), aw = fabsf(wf);
@@ -325,7 +325,7 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
         tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
       }
       if (zf < 0.0f) tf = -tf;
-      const double t = (double)tf;
+      t = (double)tf;
       const double x = 1.0 + t * t;
       c = __builtin_amdgcn_rsq(x);            // ~2^-26 relative; one Newton step squares that
       c = c * (1.5 - 0.5 * x * c * c);
@@ -333,27 +333,33 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       return true;
     };
     // cross pairs: row p = g8 stays with this 8-lane group for all kJB steps -> carried in registers; only the
-    // q rows (which move from group to group) make the LDS round trip
+    // q rows (which move from group to group) make the LDS round trip.  The diagonal entries are not recomputed
+    // as dot products: a rotation changes exactly h_pp -> h_pp - t*g and h_qq -> h_qq + t*g (t = tan), so h_pp
+    // lives in a register and h_qq travels with its row in the padding column of H; only g = h_pq is a reduction.
     {
       const int p = g8;
+      if (lane < kPair) Hs[lane][kPair] = Hs[lane][lane];        // Q = I on entry: h_ii = H[i][i]
+      wave_lds_fence();
       double2_t* yp = reinterpret_cast<double2_t*>(&Hs[p][2 * l8]);
       double2_t* tp = reinterpret_cast<double2_t*>(&Qs[p][2 * l8]);
       double2_t vp = *yp, up = *tp;
+      double a = Hs[p][kPair];
       for (int st = 0; st < kJB; ++st) {
         const int q = kJB + ((g8 + st) & (kJB - 1));
         double2_t* yq = reinterpret_cast<double2_t*>(&Hs[q][2 * l8]);
         double2_t* tq = reinterpret_cast<double2_t*>(&Qs[q][2 * l8]);
         const double2_t vq = *yq, uq = *tq;
-        const double a = group8_sum(vp.x * up.x + vp.y * up.y);
-        const double b = group8_sum(vq.x * uq.x + vq.y * uq.y);
+        const double b = Hs[q][kPair];
         const double g = group8_sum(vp.x * uq.x + vp.y * uq.y);
-        double c, s;
-        if (rotation(a, b, g, c, s)) {
+        double c, s, t;
+        if (rotation(a, b, g, c, s, t)) {
           // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
           *yq = double2_t{s * vp.x + c * vq.x, s * vp.y + c * vq.y};
           *tq = double2_t{s * up.x + c * uq.x, s * up.y + c * uq.y};
           vp = double2_t{c * vp.x - s * vq.x, c * vp.y - s * vq.y};
           up = double2_t{c * up.x - s * uq.x, c * up.y - s * uq.y};
+          if (l8 == 0) Hs[q][kPair] = b + t * g;
+          a -= t * g;
           did = 1;
         }
         wave_lds_fence();
@@ -376,8 +382,8 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       const double a = group8_sum(vp.x * up.x + vp.y * up.y);
       const double b = group8_sum(vq.x * uq.x + vq.y * uq.y);
       const double g = group8_sum(vp.x * uq.x + vp.y * uq.y);
-      double c, s;
-      if (rotation(a, b, g, c, s)) {
+      double c, s, t;
+      if (rotation(a, b, g, c, s, t)) {
         *yp = double2_t{c * vp.x - s * vq.x, c * vp.y - s * vq.y};
         *yq = double2_t{s * vp.x + c * vq.x, s * vp.y + c * vq.y};
         *tp = double2_t{c * up.x - s * uq.x, c * up.y - s * uq.y};
