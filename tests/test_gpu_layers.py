@@ -269,6 +269,33 @@ def test_tucker_batched_plan_full_resnet32_table(dev):
         assert abs(e1[-1] - e2[-1]) <= 1e-6
 
 
+def test_tucker_plan_odd_shapes_vs_oracle(dev):
+    """Shapes where an unfolding has fewer singular values than the requested rank, wide / tall linear layers and
+    1x1 convs, all in ONE plan, against the oracle restatement (parity UNPINNED: tensorly absent)."""
+    from tadmm import ops
+    rng = np.random.default_rng(12)
+    cases = [((12, 40), [5, 6]), ((40, 12), [6, 5]), ((64, 4, 1, 1), [8, 3]), ((8, 8, 3, 3), [8, 8]),
+             ((24, 20, 3, 3), [20, 4]), ((16, 48, 1, 1), [10, 12])]
+    ws = [(rng.standard_normal(s) * 0.3).astype(np.float32) for s, _ in cases]
+    layers = []
+    for w, (_, r) in zip(ws, cases):
+        t = torch.from_numpy(w).to(dev)
+        layers.append(dict(W=t, U=torch.zeros_like(t), Z=torch.empty_like(t), ranks=r))
+    plan = ops.TuckerPlan(layers)
+    resid = plan.run(update_u=True).cpu().numpy()
+    for i, (w, (shape, r)) in enumerate(zip(ws, cases)):
+        z = O.prune_rank_tk(w, r)
+        got = layers[i]["Z"].cpu().numpy()
+        rel = np.linalg.norm(got - z) / max(np.linalg.norm(z), 1e-30)
+        assert rel <= 5e-5, (shape, r, rel)
+        np.testing.assert_allclose(layers[i]["U"].cpu().numpy(), w - got, atol=1e-6)
+        assert abs(resid[i] - np.linalg.norm((w - got).astype(np.float64)) ** 2) <= 1e-5 * max(resid[i], 1e-12) + 1e-10
+        core, u_out, u_in = plan.factors(i)
+        assert tuple(core.shape)[:2] == (r[0], r[1]) and tuple(u_out.shape) == (shape[0], r[0]) and \
+            tuple(u_in.shape) == (shape[1], r[1])
+    plan.close()
+
+
 def test_decompose_state_dict_handoff(dev):
     """--decompose hand-off: dense *_model.pt state_dict -> factorised state_dict (reference keys), all table
     layers in one grouped device plan; loads into the layer classes and reproduces their forwards."""
