@@ -114,6 +114,10 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        # PyTorch-ROCm ships its own libamdhip64; import it FIRST so that this library's HIP calls resolve to the
+        # same runtime instance that owns torch's device memory and streams (loading the system runtime first
+        # leaves the process with a runtime torch then cannot see a device through)
+        import torch  # noqa: F401
         path = library_path()
         if not os.path.exists(path):
             raise TadmmLibraryError(
