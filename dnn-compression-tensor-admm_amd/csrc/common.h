@@ -123,6 +123,9 @@ constexpr int kGemmBM = 64, kGemmBN = 64;
 void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                  const int32_t* skip = nullptr);
 void launch_gemm_one(const GemmDesc& d, hipStream_t s);   // descriptor passed as a kernel argument
+// bf16 C[M][N] = A[M][K] * Bt[N][K]^T (+ f32 bias over N), fp32 accumulate (gemm_bf16.hip)
+void launch_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                         int64_t ldc, const float* bias_n, hipStream_t s);
 
 // ---------------------------------------------------------------- penalty
 constexpr int kPenaltyBlocks = 1024;

@@ -869,6 +869,15 @@ int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* sdesc, void* stream_) {
   return TADMM_OK;
 }
 
+int tadmm_gemm_bf16_nt(tadmm_handle h, const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda,
+                       int64_t ldb, int64_t ldc, const float* bias_n, void* stream_) {
+  if (!h || !A || !Bt || !C) return TADMM_ERR_INVALID;
+  if (M <= 0 || N <= 0 || K <= 0 || lda < K || ldb < K || ldc < N) CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_gemm_bf16_nt: bad shape");
+  launch_gemm_bf16_nt(A, Bt, C, M, N, K, lda, ldb, ldc, bias_n, (hipStream_t)stream_);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
 // ---- standalone Gram / eigh (tests, Tucker path) ----
 static void gram_geom(int m, int n, StepGeom& st) {
   st.m = m; st.cols = n; st.trans = m > n;

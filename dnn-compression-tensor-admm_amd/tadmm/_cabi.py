@@ -91,6 +91,8 @@ ABI = {
     "tadmm_gemm_pack": (C.c_int, [C.c_int, C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "tadmm_gemm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "tadmm_gemm": (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_void_p]),
+    "tadmm_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "tadmm_gram_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "tadmm_gram_ld": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tadmm_gram_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -278,6 +278,28 @@ def mm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, alp
     return out
 
 
+def mm_nt_bf16(a: torch.Tensor, bt: torch.Tensor, bias_n: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a (M,K) @ bt (N,K)^T [+ bias over N] in bf16 with fp32 accumulation; rows contiguous along K."""
+    assert a.dim() == 2 and bt.dim() == 2 and a.shape[1] == bt.shape[1]
+    for t, what in ((a, "a"), (bt, "bt")):
+        if not t.is_cuda:
+            raise TadmmError(-1, f"{what} must live on a HIP device; there is no CPU path")
+        if t.dtype != torch.bfloat16:
+            raise TadmmError(-1, f"{what} must be bfloat16")
+        if t.stride(1) != 1:
+            raise TadmmError(-1, f"{what} must be contiguous along K")
+    M, K = a.shape
+    N = bt.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    if bias_n is not None:
+        bias_n = bias_n.float().contiguous()
+    dev = a.device
+    h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    h.check(h.lib.tadmm_gemm_bf16_nt(h.ptr, a.data_ptr(), bt.data_ptr(), out.data_ptr(), M, N, K, a.stride(0),
+                                     bt.stride(0), N, None if bias_n is None else bias_n.data_ptr(), _stream(dev)))
+    return out
+
+
 # ------------------------------------------------------------------ Gram / eigh (tests, Tucker)
 def gram(a: torch.Tensor):
     """fp64 Gram of a float32 (m,n) matrix: A A^T if m<=n else A^T A.  Returns (N,N) float64."""

@@ -283,6 +283,8 @@ class TTLinearM(_TTLinearBase):
         self._init_cores()
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or self.tt_cores[0].requires_grad)):
+            return self._forward_bf16(x)
         out_shape = list(x.shape)
         out_shape[-1] = self.out_features
         q = self.out_tt_order
@@ -297,6 +299,28 @@ class TTLinearM(_TTLinearBase):
         out = out.reshape(self.out_features, -1).t().reshape(out_shape)
         if self.bias is not None:
             out = out + self.bias
+        return out
+
+    def _forward_bf16(self, x):
+        """Inference in bfloat16 (the reference reaches this through AMP autocast, engines.py:285-289): the same
+        chain, every product `A * Bt^T` with both operands contiguous along K, on the bf16 matrix cores with fp32
+        accumulation (`tadmm_gemm_bf16_nt`); intermediate activations stay in bf16."""
+        from . import ops
+        out_shape = list(x.shape)
+        out_shape[-1] = self.out_features
+        q = self.out_tt_order
+        cores = [c.detach().to(torch.bfloat16) for c in self.tt_cores]
+        out = x
+        for i in range(self.in_tt_order - 1, -1, -1):
+            k = self.in_tt_shapes[i] * self.tt_ranks[i + q + 1]
+            out = ops.mm_nt_bf16(out.reshape(-1, k).contiguous(), cores[i + q].reshape(-1, k))
+        for i in range(q - 1, -1, -1):
+            r1 = self.tt_ranks[i + 1]
+            out = ops.mm_nt_bf16(cores[i].reshape(-1, r1), out.reshape(-1, r1).contiguous())
+            out = out.reshape(self.tt_ranks[i], -1).t()
+        out = out.reshape(self.out_features, -1).t().reshape(out_shape)
+        if self.bias is not None:
+            out = out + self.bias.to(torch.bfloat16)
         return out
 
 

@@ -172,6 +172,11 @@ int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, voi
 /* One GEMM, descriptor passed by value to the kernel (no upload): the per-call path of the layers' forward and
  * backward products (TTLinear.py:79-86, TTConv.py:133-147, TKConv.py:210-214, TKLinear.py:66-71). */
 int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* desc, void* stream);
+/* bf16 inference path of the TT-linear chain (TTLinear.py:79-86; every product there is A * Bt^T with both
+ * operands contiguous along K):  C[M][N] = A[M][K] * Bt[N][K]^T (+ bias_n[j]), bf16 in / bf16 out, fp32
+ * accumulate on the matrix cores.  lda / ldb / ldc in elements. */
+int tadmm_gemm_bf16_nt(tadmm_handle h, const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda,
+                       int64_t ldb, int64_t ldc, const float* bias_n, void* stream);
 
 /* G = A A^T (m<=n) or A^T A (m>n) of a row-major float32 m x n matrix, exact fp32 products
  * accumulated in fp64 on v_mfma_f64_16x16x4_f64.  G is written as double[Npad][ldg] (zero padded; see tadmm_gram_ld), N=min(m,n).

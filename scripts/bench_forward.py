@@ -59,6 +59,13 @@ def main():
         ms = timeit(lambda: tk(xk))
         msd = timeit(lambda: F.conv2d(xk, wk, None, 1, 1))
     print("TKConv2dC  resnet32 %s B=128: %.3f ms   dense conv2d fp32 %.3f ms" % (n32, ms, msd))
+    # --- bf16 inference path of TTLinearM (last: the bf16 library calls of the dense baseline change MIOpen's
+    # algorithm choice for the convolutions above when they run first)
+    with torch.no_grad():
+        xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+        msb = timeit(lambda: lin(xb))
+        msdb = timeit(lambda: F.linear(xb, wb))
+    print("TTLinearM  deit_small qkv   T=%d bf16: %.3f ms   dense F.linear bf16 %.3f ms" % (T, msb, msdb))
 
 
 if __name__ == "__main__":

@@ -125,3 +125,39 @@ def test_tucker_plan_is_deterministic_and_batches_mixed_layers(dev):
     for ua, ub in zip(outs[0][1], outs[1][1]):
         assert torch.equal(ua, ub)
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 70, 25), (12608, 288, 24), (257, 129, 300), (1, 5, 3)])
+def test_gemm_bf16_nt(dev, M, N, K):
+    """bf16 A * Bt^T with fp32 accumulation against torch on the same bf16 inputs (result rounded to bf16 once)."""
+    from tadmm import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    bt = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    got = ops.mm_nt_bf16(a, bt, bias).float().cpu()
+    ref = (a.float().cpu().double() @ bt.float().cpu().double().T + bias.cpu().double())
+    err = (got.double() - ref).abs()
+    # one bf16 rounding of the result (2^-8 relative) + fp32 accumulation noise
+    assert float((err / (ref.abs() + 1e-2 * ref.abs().max())).max()) <= 6e-3
+
+
+@pytest.mark.gpu
+def test_ttlinear_bf16_forward_matches_fp32(dev):
+    from tadmm import tt_layers
+
+    class HP:
+        tt_shapes = {"w": (6, 8, 4, 6)}
+        ranks = {"w": (1, 5, 16, 5, 1)}
+    lin = tt_layers.TTLinearM(24, 48, bias=True, hp_dict=HP, name="w").to(dev)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():    # like the reference (TTLinear.py:55), TTLinearM leaves a fresh bias uninitialised
+        lin.bias.copy_(torch.randn(48, generator=g))
+    x = torch.randn(7, 33, 24, generator=g).to(dev)
+    with torch.no_grad():
+        ref = lin(x)
+        got = lin(x.to(torch.bfloat16))
+    assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+    rel = float((got.float() - ref).norm() / ref.norm())
+    assert rel <= 2e-2, rel
