@@ -459,12 +459,22 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   {
     const int c2n = ld >> 1;                       // double2 chunks per row
     const int total = kPair * c2n;
-#pragma unroll 4
-    for (int idx = tid; idx < total; idx += 256) {
-      const int row = idx / c2n, c2 = idx - row * c2n;
-      const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
-      const double2_t v = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
-      *reinterpret_cast<double2_t*>(Xs + row * ldp + 2 * c2) = v;
+    constexpr int kBatch = 8;                      // 16-byte loads in flight per thread (latency-bound phase)
+    for (int base = tid; base < total; base += 256 * kBatch) {
+      double2_t v[kBatch];
+      int dst[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int idx = base + k * 256;
+        const bool ok = idx < total;
+        const int row = ok ? idx / c2n : 0, c2 = ok ? idx - row * c2n : 0;
+        const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
+        dst[k] = ok ? row * ldp + 2 * c2 : -1;
+        v[k] = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
+      }
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k)
+        if (dst[k] >= 0) *reinterpret_cast<double2_t*>(Xs + dst[k]) = v[k];
     }
   }
   __syncthreads();
@@ -812,14 +822,26 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   // ---- load the 32 columns; fetch the two carried self-Grams into registers ----
   const double sreg = d.sblk[(int64_t)(tid < 256 ? sa : sb) * (kPair * kPair) + th];
   {
+    constexpr int kLoadBatch = 8;
+    // 128 KiB per workgroup: keep kLoadBatch x 16 bytes per thread in flight (all loads of a batch are issued before the
+    // first LDS store waits on them) -- the load phase is latency-, not bandwidth-bound
     const int c2n = ld >> 1;
-    const int total = kSuper * c2n;
-#pragma unroll 4
-    for (int idx = tid; idx < total; idx += 512) {
-      const int row = idx / c2n, c2 = idx - row * c2n;
-      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
-      const double2_t v = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
-      *reinterpret_cast<double2_t*>(Xs + row * ldp + 2 * c2) = v;
+    const int total = kSuper * c2n;                  // multiple of 512 * 2 (ld % 64 == 0)
+    for (int base = tid; base < total; base += 512 * kLoadBatch) {
+      double2_t v[kLoadBatch];
+      int dst[kLoadBatch];
+#pragma unroll
+      for (int k = 0; k < kLoadBatch; ++k) {
+        const int idx = base + k * 512;
+        const bool ok = idx < total;
+        const int row = ok ? idx / c2n : 0, c2 = ok ? idx - row * c2n : 0;
+        const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
+        dst[k] = ok ? row * ldp + 2 * c2 : -1;
+        v[k] = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + 2 * c2);
+      }
+#pragma unroll
+      for (int k = 0; k < kLoadBatch; ++k)
+        if (dst[k] >= 0) *reinterpret_cast<double2_t*>(Xs + dst[k]) = v[k];
     }
   }
   __syncthreads();
