@@ -785,19 +785,12 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const BlockRef br = map[blockIdx.x];
   const EigDesc d = descs[br.prob];
-  if (*d.done) return;
   const int nbs = d.nb >> 1;
   const int steps = nbs - 1;
   const int sweep = tick / steps;
   const int step = tick - sweep * steps;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = wave >> 2, wv = wave & 3, th = tid & 255;
-  if (step == 0 && sweep > 0) {
-    if (d.off[(sweep - 1) & 1] < tol) {
-      if (br.local == 0 && tid == 0) *d.done = 1;
-      return;
-    }
-  }
   const int ld = d.ld, ldp = ld + 2;
 #ifdef TADMM_STAMPS
   const unsigned long long t0 = clock64();
@@ -819,14 +812,45 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   const int r = lane & 15, q = lane >> 4;
   double* __restrict__ XT = d.XT;
 
-  // ---- load the 32 columns; fetch the two carried self-Grams into registers ----
-  const double sreg = d.sblk[(int64_t)(tid < 256 ? sa : sb) * (kPair * kPair) + th];
+  // ---- load the 32 columns ----
+  const bool dma = (ld & 127) == 0;
+  if (dma) {
+    // LDS-DMA (global_load_lds_dwordx4): a wave moves 1 KiB chunks of a column straight into LDS -- 64 lanes x
+    // 16 bytes land at consecutive LDS addresses behind a wave-uniform base, no staging registers, so all 16
+    // chunks of a wave are in flight at once (the phase is latency-, not bandwidth-bound).  Rows are whole
+    // 1 KiB chunks (ld % 128 == 0) and an LDS row starts 16 bytes after the previous one ends (ldp = ld + 2).
+    // Issued before the convergence flags are even read: their load latency hides behind the columns'.
+    const int cpr = ld >> 7;                          // chunks per column
+    const int nchunk = kSuper * cpr;
+    for (int c = wave; c < nchunk; c += 8) {
+      const int row = c / cpr, ch = c - row * cpr;
+      const int grow = (row < kPair) ? (sa * kPair + row) : (sb * kPair + (row - kPair));
+      const double* src = XT + (int64_t)grow * ld + ch * 128 + lane * 2;
+      double* dst = Xs + row * ldp + ch * 128;        // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
   {
+    bool quit = *d.done != 0;
+    if (!quit && step == 0 && sweep > 0 && d.off[(sweep - 1) & 1] < tol) {
+      if (br.local == 0 && tid == 0) *d.done = 1;
+      quit = true;
+    }
+    if (quit) {                                       // uniform over the workgroup
+      if (dma) __builtin_amdgcn_s_waitcnt(0);         // no DMA may still target this workgroup's LDS at exit
+      return;
+    }
+  }
+  // the two carried self-Grams go to registers
+  const double sreg = d.sblk[(int64_t)(tid < 256 ? sa : sb) * (kPair * kPair) + th];
+  if (dma) {
+    __builtin_amdgcn_s_waitcnt(0);
+  } else {
     constexpr int kLoadBatch = 8;
-    // 128 KiB per workgroup: keep kLoadBatch x 16 bytes per thread in flight (all loads of a batch are issued before the
-    // first LDS store waits on them) -- the load phase is latency-, not bandwidth-bound
+    // register-staged path: keep kLoadBatch x 16 bytes per thread in flight
     const int c2n = ld >> 1;
-    const int total = kSuper * c2n;                  // multiple of 512 * 2 (ld % 64 == 0)
+    const int total = kSuper * c2n;
     for (int base = tid; base < total; base += 512 * kLoadBatch) {
       double2_t v[kLoadBatch];
       int dst[kLoadBatch];
