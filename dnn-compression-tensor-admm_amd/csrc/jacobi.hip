@@ -80,23 +80,18 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 // Scratch of one pair visit (all in LDS)
 struct PairScratch {
   double* red;            // [4][256] cross-wave partials of H
-  double (*H)[kHP];       // [16][17]
-  double (*Q)[kHP];       // [16][17]
-  double* cA; double* cB; // [16] rotation coefficients per index
-  int* pt;                // [16] partner index
+  double (*H)[kHP];       // [16][18]: H on entry, Y = Q^T H while solving; column 16 carries h_qq of the row
+  double (*Q)[kHP];       // [16][18]: Q^T while solving
   int* rotated;           // [1]
 };
-constexpr int kPairScratchDoubles = 4 * 256 + 2 * kPair * kHP + 2 * kPair + kPair / 2 + 2;
+constexpr int kPairScratchDoubles = 4 * 256 + 2 * kPair * kHP + 2;
 
 __device__ __forceinline__ PairScratch carve_scratch(double* base) {
   PairScratch s;
   s.red = base;
   s.H = reinterpret_cast<double (*)[kHP]>(base + 4 * 256);
   s.Q = s.H + kPair;
-  s.cA = reinterpret_cast<double*>(s.Q + kPair);
-  s.cB = s.cA + kPair;
-  s.pt = reinterpret_cast<int*>(s.cB + kPair);
-  s.rotated = s.pt + kPair;
+  s.rotated = reinterpret_cast<int*>(s.Q + kPair);
   return s;
 }
 
@@ -120,110 +115,6 @@ __device__ __forceinline__ void pair_gram_reduce(const PairScratch& S, int t) {
   const int hr = (l >> 4) + 4 * reg, hc = l & 15;
   S.H[hr][hc] = (S.red[t] + S.red[256 + t]) + (S.red[512 + t] + S.red[768 + t]);
   S.Q[hr][hc] = (hr == hc) ? 1.0 : 0.0;
-}
-
-// One wave: convergence measure + one cyclic sweep of two-sided Jacobi on H (accumulating Q).
-//   within: also rotate the 2 x 28 index pairs inside each block of 8 (15 parallel steps instead of 8)
-// Returns the measure (same value on all lanes); sets *S.rotated.
-__device__ __forceinline__ double pair_inner_solve(const PairScratch& S, int lane, double hmax, double tol,
-                                                   bool within, int inner_sweeps) {
-  double (*Hs)[kHP] = S.H;
-  double (*Qs)[kHP] = S.Q;
-  const double inv_hmax = hmax > 0.0 ? 1.0 / hmax : 1.0;   // keeps the fp32 estimates in range
-  // The measure only gates convergence (it is compared with tol with orders of magnitude of margin), so it is
-  // evaluated in fp32 fast math on entries scaled by 1/hmax: r_i = h_ii/hmax lies in (1e-28, 1].
-  const float wscale = (float)(1e-14 / tol);
-  float mxf = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = lane * 4 + k;
-    const int i = e >> 4, j = e & 15;
-    if (i < j) {
-      const float ri = (float)(Hs[i][i] * inv_hmax), rj = (float)(Hs[j][j] * inv_hmax);
-      const float rmin = fminf(ri, rj);
-      if (rmin > 1e-28f) {                                  // lambda < 1e-14 lambda_max: padding / exact zeros
-        const float hij = fabsf((float)(Hs[i][j] * inv_hmax));
-        const float w = fmaxf(1.0f, wscale * __builtin_amdgcn_rsqf(rmin));        // lambda_max / lambda_min
-        mxf = fmaxf(mxf, hij * __builtin_amdgcn_rsqf(ri) * __builtin_amdgcn_rsqf(rj) * __builtin_amdgcn_rcpf(w));
-      }
-    }
-  }
-  double mx = (double)mxf;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
-  mx = __shfl(mx, 0, 64);
-  int did = 0;
-  if (mx > 1e-15) {
-    // rotation schedule: the 8x8 = 64 cross-block pairs in 8 parallel steps (i, 8 + (i+st)%8); then,
-    // if `within`, 7 steps of round robin inside each block (lanes 0-3 block A, 4-7 block B)
-    const int nsteps = within ? (kJB + kJB - 1) : kJB;
-    for (int isw = 0; isw < inner_sweeps; ++isw) {
-      for (int st = 0; st < nsteps; ++st) {
-        if (lane < kPair / 2) {
-          int p, qq;
-          if (st < kJB) { p = lane; qq = kJB + ((lane + st) & (kJB - 1)); }
-          else {
-            int a2, b2;
-            rr_pair(kJB, st - kJB, lane & 3, a2, b2);
-            const int base = (lane >> 2) * kJB;
-            p = base + min(a2, b2); qq = base + max(a2, b2);
-          }
-          const double hpp = Hs[p][p], hqq = Hs[qq][qq], hpq = Hs[p][qq];
-          double c = 1.0, s = 0.0;
-          if (hpq * hpq > 1e-36 * fabs(hpp * hqq) && fabs(hpq) > 1e-300) {
-            // tan(theta) of the small-angle root, t = w sgn(z) / (|z| + sqrt(z^2 + w^2)), z = hqq-hpp, w = 2hpq.
-            // Only the *orthogonality* of the rotation must be exact: t is estimated in fp32 (the pair is
-            // annihilated to ~1e-7 relative, i.e. >= 7 more digits per sweep -- the quadratic phase is not
-            // slowed), then c = (1+t^2)^-1/2 is refined to fp64 so that c^2 + s^2 = 1 to rounding.
-            const float zf = (float)((hqq - hpp) * inv_hmax), wf = (float)(2.0 * hpq * inv_hmax);
-            const float az = fabsf(zf), aw = fabsf(wf);
-            float tf;
-            if (az >= aw) {
-              const float u = wf * __builtin_amdgcn_rcpf(az);                 // |u| <= 1
-              tf = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + u * u));
-            } else {
-              const float v = az * __builtin_amdgcn_rcpf(aw);                 // v < 1
-              tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
-            }
-            if (zf < 0.0f) tf = -tf;
-            const double t = (double)tf;
-            const double x = 1.0 + t * t;                                     // in [1, 2]
-            double y = __builtin_amdgcn_rsq(x);
-            y = y * (1.5 - 0.5 * x * y * y);
-            y = y * (1.5 - 0.5 * x * y * y);
-            c = y;
-            s = t * c;
-            did = 1;
-          }
-          // new_p = c*old_p - s*old_q ; new_q = s*old_p + c*old_q
-          S.cA[p] = c; S.cB[p] = -s; S.pt[p] = qq;
-          S.cA[qq] = c; S.cB[qq] = s; S.pt[qq] = p;
-        }
-        wave_lds_fence();
-        double nh[4], nq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = lane * 4 + k;
-          const int i = e >> 4, j = e & 15;
-          const int is = S.pt[i], js = S.pt[j];
-          const double ai = S.cA[i], bi = S.cB[i], aj = S.cA[j], bj = S.cB[j];
-          nh[k] = ai * (aj * Hs[i][j] + bj * Hs[i][js]) + bi * (aj * Hs[is][j] + bj * Hs[is][js]);
-          nq[k] = aj * Qs[i][j] + bj * Qs[i][js];
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = lane * 4 + k;
-          Hs[e >> 4][e & 15] = nh[k];
-          Qs[e >> 4][e & 15] = nq[k];
-        }
-        wave_lds_fence();
-      }
-    }
-    did = __any(did);
-  }
-  if (lane == 0) *S.rotated = did;
-  return mx;
 }
 
 // ---- DPP helpers (row = 16 lanes) ----
@@ -488,10 +379,8 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   pair_gram_reduce(S, tid);
   __syncthreads();
   if (wave == 0) {
-    const bool fast = (inner_sweeps == 1);
     double* hcur = (self_mode && d.sblk) ? d.sblk + (int64_t)br.local * (kPair * kPair) : nullptr;
-    const double mx = (fast || hcur) ? pair_inner_solve_fast(S, lane, d.off[2], tol, step == 0, hcur)
-                                     : pair_inner_solve(S, lane, d.off[2], tol, step == 0, inner_sweeps & 15);
+    const double mx = pair_inner_solve_fast(S, lane, d.off[2], tol, step == 0, hcur);
     if (lane == 0)
       atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mx));
   }
@@ -584,7 +473,6 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
   if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
 
   const double hmax = d.off[2];
-  const bool fast = (inner_sweeps == 1);     // row formulation of the inner solve (default)
   const int per = ld >> 2;
   double mxall = 0.0;
   int any_rot = 0;
@@ -604,8 +492,7 @@ __global__ __launch_bounds__(512) void jacobi_tick2_kernel(const EigDesc* __rest
     __syncthreads();
     STAMP(2 + 4 * round);
     if (wv == 0) {
-      const double mx = fast ? pair_inner_solve_fast(S, lane, hmax, tol, round == 0)
-                             : pair_inner_solve(S, lane, hmax, tol, round == 0, inner_sweeps & 15);
+      const double mx = pair_inner_solve_fast(S, lane, hmax, tol, round == 0);
       mxall = fmax(mxall, mx);
     }
     __syncthreads();

@@ -146,7 +146,7 @@ struct StepPlan {
   int ld_max = 0;
   int npad_max = 0;
   size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
-  size_t prev_off_dev = 0, alldone_off = 0;   // [neig] doubles of the convergence kernel / its verdict (int)
+  size_t prev_off_dev = 0;            // [neig] doubles of the convergence kernel
   std::vector<int> nb;            // per problem
   std::vector<int> layer_of;      // problem -> layer
 };
@@ -172,9 +172,6 @@ struct tadmm_plan_s {
   PollCtx poll;                   // pipelined convergence poll (host.h)
   double last_ms[8] = {0};
   int last_sweeps = 0;
-  // host staging for the poll
-  std::vector<double> h_off;
-  std::vector<int> h_done;
   double tol = 1e-9;
   int inner_sweeps = 1;
   bool debug = false;
@@ -349,7 +346,6 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     sp.off_off = ar.take((size_t)std::max(1, sp.neig) * 3 * 8);
     sp.done_off = ar.take((size_t)std::max(1, sp.neig) * 4);
     sp.prev_off_dev = ar.take((size_t)std::max(1, sp.neig) * 8);
-    sp.alldone_off = ar.take(16);
     sp.gsteps = 0;
     for (int p = 0; p < sp.neig; ++p) {
       const int l = layer_of[p];
@@ -654,11 +650,8 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
   }
   if (const char* e = getenv("TADMM_JACOBI_TOL")) P->tol = atof(e);
   if (getenv("TADMM_DEBUG")) P->debug = true;
-  if (const char* e = getenv("TADMM_JACOBI_INNER")) P->inner_sweeps = atoi(e);
   size_t maxe = 1;
   for (const StepPlan& sp : P->steps) maxe = std::max<size_t>(maxe, sp.neig);
-  P->h_off.resize(maxe * 3);
-  P->h_done.resize(maxe);
   {
     const hipError_t e = P->poll.create(maxe);
     if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "poll buffers: %s", hipGetErrorString(e)); }

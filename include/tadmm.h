@@ -112,8 +112,9 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
 int tadmm_plan_last_timing(tadmm_plan p, double out_ms[8]);
 int tadmm_plan_enable_timing(tadmm_plan p, int on);
 /* Jacobi tunables: tol = largest relative off-diagonal a sweep may observe and still be the last one
- * (quadratic convergence leaves ~tol^2 afterwards; default 1e-9), inner_sweeps = cyclic sweeps on each
- * 16x16 pair Gram per visit (default 3), max_sweeps = cap before TADMM_ERR_NOCONVERGE.  <=0 keeps a value. */
+ * (quadratic convergence leaves ~tol^2 afterwards; default 1e-9), inner_sweeps = reserved (the 16x16
+ * sub-problems always get one cyclic sweep per visit), max_sweeps = cap before TADMM_ERR_NOCONVERGE.
+ * <=0 keeps a value. */
 int tadmm_plan_set_jacobi(tadmm_plan p, double tol, int inner_sweeps, int max_sweeps);
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
