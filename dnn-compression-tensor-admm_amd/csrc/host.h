@@ -96,6 +96,7 @@ struct EigGroup {
   double* prev_dev = nullptr;       // [neig] scratch of the convergence kernel
   const int32_t* skip = nullptr;    // optional per-problem predicate (non-zero: the problem is dropped)
   int npad_max = 0;                 // largest padded problem size (<= 64: single-launch solver)
+  int expected = 0;                 // sweeps the previous run of this group needed (0: unknown)
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
 };
@@ -166,11 +167,18 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
       }
       fprintf(stderr, "[tadmm]   sweep %d: max observed off %.3e, done %d/%d\n", gs, mxo, nd, g.neig);
     }
-    const int rc = consume();               // verdict of the previous sweep (long since on the host)
+    int rc = consume();                     // verdict of the previous sweep (long since on the host)
     if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
     if (all_done) break;
     HIP_OK(h, hipEventRecord(poll.ev[gs & 1], s));
     pending = gs;
+    if (g.expected > 0 && gs + 1 >= g.expected) {
+      // Jacobi needs about the same number of sweeps from one ADMM iteration to the next: from the sweep that
+      // was the last one last time, wait for the verdict (one short stall) instead of queueing a sweep of
+      // launches that would most likely find every problem finished.
+      rc = consume();
+      if (rc != TADMM_OK) CTX_FAIL(h, rc, "poll event failed");
+    }
   }
   if (!all_done) {
     const int rc = consume();

@@ -719,6 +719,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     eg.prev_dev = (double*)D(sp.prev_off_dev);
     eg.off_dev = (const double*)D(sp.off_off); eg.done_dev = (const int*)D(sp.done_off);
     eg.npad_max = sp.npad_max;
+    eg.expected = sp.last_sweeps;
     int gs = 0;
     bool small_pending = false;
     {
