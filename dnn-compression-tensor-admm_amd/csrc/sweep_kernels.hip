@@ -203,7 +203,25 @@ __global__ __launch_bounds__(kSweepThreads) void penalty_kernel(int n, const voi
     const float* z = (const float*)ptrs[n + layer];
     const float* u = (const float*)ptrs[2 * n + layer];
     float* g = (float*)ptrs[3 * n + layer];
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += kSweepThreads) {
+    // 16-byte accesses on the aligned middle of the segment (torch allocations are 256-byte aligned and `per` is
+    // a multiple of 4, so whole layers take this path), scalar head / tail otherwise
+    const bool al = ((((uintptr_t)w) | ((uintptr_t)z) | ((uintptr_t)u) | ((uintptr_t)g)) & 15) == 0;
+    const int64_t v0 = al ? min(e1, (e0 + 3) & ~(int64_t)3) : e1;       // first 4-aligned element
+    const int64_t v1 = al ? (v0 + ((e1 - v0) & ~(int64_t)3)) : e1;       // end of the vector part
+    for (int64_t e = e0 + threadIdx.x; e < v0; e += kSweepThreads) {
+      const float dlt = w[e] - z[e] + u[e];
+      acc += (double)dlt * dlt;
+      if (g) g[e] = gscale * dlt;
+    }
+    for (int64_t e = v0 + 4 * (int64_t)threadIdx.x; e < v1; e += 4 * kSweepThreads) {
+      const float4 a = *reinterpret_cast<const float4*>(w + e);
+      const float4 b = *reinterpret_cast<const float4*>(z + e);
+      const float4 c = *reinterpret_cast<const float4*>(u + e);
+      const float4 dl = make_float4(a.x - b.x + c.x, a.y - b.y + c.y, a.z - b.z + c.z, a.w - b.w + c.w);
+      acc += ((double)dl.x * dl.x + (double)dl.y * dl.y) + ((double)dl.z * dl.z + (double)dl.w * dl.w);
+      if (g) *reinterpret_cast<float4*>(g + e) = make_float4(gscale * dl.x, gscale * dl.y, gscale * dl.z, gscale * dl.w);
+    }
+    for (int64_t e = v1 + threadIdx.x; e < e1; e += kSweepThreads) {
       const float dlt = w[e] - z[e] + u[e];
       acc += (double)dlt * dlt;
       if (g) g[e] = gscale * dlt;

@@ -85,7 +85,14 @@ class ADMM:
         raise Exception('ERROR: unsupported layer in ADMM!')                    # admm.py:69
 
     def _named(self):
-        return [(n, p) for n, p in self.model.named_parameters() if n in self.hp_dict.ranks]
+        # The table's parameters, in model order.  Cached: walking named_parameters() of a full network on every
+        # training step (append_admm_loss) costs more host time than the fused penalty launch takes on the GPU;
+        # the Parameter objects are stable (`.data` swaps are caught by the data_ptr keys).
+        c = getattr(self, "_named_cache", None)
+        if c is None:
+            c = [(n, p) for n, p in self.model.named_parameters() if n in self.hp_dict.ranks]
+            self._named_cache = c
+        return c
 
     def _build(self):
         named = self._named()
