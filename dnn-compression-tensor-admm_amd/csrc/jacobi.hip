@@ -346,8 +346,21 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   const int r = lane & 15, q = lane >> 4;
   double* __restrict__ XT = d.XT;
 
-  // ---- 0. stage the pair's 16 columns (rows of XT) in LDS: one burst of 16-byte loads ----
-  {
+  // ---- 0. stage the pair's 16 columns (rows of XT) in LDS ----
+  if ((ld & 127) == 0) {
+    // LDS-DMA, 1 KiB chunks, every chunk of a wave in flight at once (see jacobi_tick3_kernel)
+    const int cpr = ld >> 7;
+    const int nchunk = kPair * cpr;
+    for (int c = wave; c < nchunk; c += 4) {
+      const int row = c / cpr, ch = c - row * cpr;
+      const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
+      const double* src = XT + (int64_t)grow * ld + ch * 128 + lane * 2;
+      double* dst = Xs + row * ldp + ch * 128;        // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+  } else {
     const int c2n = ld >> 1;                       // double2 chunks per row
     const int total = kPair * c2n;
     constexpr int kBatch = 8;                      // 16-byte loads in flight per thread (latency-bound phase)
