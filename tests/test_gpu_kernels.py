@@ -58,7 +58,7 @@ def test_gram_fp64_exact_products(dev, m, n):
     assert np.array_equal(G, G.T)   # bitwise symmetric by construction
 
 
-@pytest.mark.parametrize("N", [5, 16, 30, 75, 130, 256, 300])
+@pytest.mark.parametrize("N", [5, 16, 30, 75, 130, 256, 300, 600, 1100])      # 600 / 1100: pair-kernel fallbacks
 @pytest.mark.parametrize("kind", ["gauss", "decay"])
 def test_eigh_jacobi(dev, N, kind):
     from tadmm import ops
