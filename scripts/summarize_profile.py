@@ -39,6 +39,25 @@ for tag, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE
     for name, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:12]:
         print("| %s | %d | %.1f | %.1f |" % (name[:60], n, tot / n, tot / 1024))
 
+# matrix-core utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (kernel cycles * 1024 SIMDs);
+# GRBM_GUI_ACTIVE comes back summed over the 8 XCDs, so kernel cycles = GRBM_GUI_ACTIVE / 8
+fm = find("pmc_mfma/**/*counter_collection.csv")
+if fm:
+    acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for row in csv.DictReader(open(fm)):
+        name = row["Kernel_Name"].split("(")[0].replace("tadmm::", "")
+        a = acc[name]
+        if row.get("Counter_Name") == "SQ_VALU_MFMA_BUSY_CYCLES":
+            a[0] += 1; a[1] += float(row["Counter_Value"])
+        elif row.get("Counter_Name") == "GRBM_GUI_ACTIVE":
+            a[2] += float(row["Counter_Value"])
+    print("\n## matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs)\n")
+    print("| kernel | launches | MFMA busy cycles per launch (all SIMDs) | kernel cycles per launch | matrix pipe busy % |")
+    print("|---|---|---|---|---|")
+    for name, (n, busy, act) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:8]:
+        if n == 0 or act == 0: continue
+        print("| %s | %d | %.0f | %.0f | %.1f |" % (name[:60], n, busy / n, act / n / 8, 100.0 * busy / (act / 8 * 1024)))
+
 # machine-readable per-launch HBM traffic (bench.py reads profiles/r01_pmc_traffic.json for roofline.traffic)
 ff, fw = find("pmc_fetch/**/*counter_collection.csv"), find("pmc_write/**/*counter_collection.csv")
 if ff and fw:
