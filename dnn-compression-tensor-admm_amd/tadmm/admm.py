@@ -29,7 +29,7 @@ class _PenaltyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, admm, loss, *params):
         val, grads = admm._penalty_forward(params)
-        ctx.grads = grads
+        ctx.grads = grads          # views of a buffer allocated for THIS call (a second forward cannot clobber them)
         ctx.n = len(params)
         return loss + val.to(loss.dtype)
 
@@ -46,6 +46,11 @@ class ADMM:
         self.hp_dict = hp_dict
         self.format = format
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            # the reference passes torch.device(args.device) with the default '--device cuda' (engines.py:69,
+            # :242); parameters report 'cuda:<index>', so resolve the index once instead of failing the
+            # device comparison in _build
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.verbose = verbose
         self.log = log
         self.process_group = process_group
@@ -215,12 +220,17 @@ class ADMM:
         dev = self.device
         key = tuple(p.data_ptr() for p in params)
         if self._pen is None or self._pen["key"] != key:
-            grads = [torch.empty_like(p.data) for p in params]
-            ptrs = [p.data_ptr() for p in params] + [self.z[k].data_ptr() for k in names] + \
-                   [self.u[k].data_ptr() for k in names] + [g.data_ptr() for g in grads]
             numel = [p.numel() for p in params]
+            # gradient slots: byte offsets inside one flat buffer that is allocated per call (64-byte aligned)
+            goff, o = [], 0
+            for k in numel:
+                goff.append(o)
+                o += (k * 4 + 63) // 64 * 64
+            ptrs = [p.data_ptr() for p in params] + [self.z[k].data_ptr() for k in names] + \
+                   [self.u[k].data_ptr() for k in names] + [0] * n
             h = ops.Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
-            self._pen = dict(key=key, grads=grads, h=h,
+            self._pen = dict(key=key, h=h, gbytes=o, goff=goff, shapes=[tuple(p.shape) for p in params], nel=numel,
+                             goff_dev=torch.tensor(goff, dtype=torch.int64).to(dev),
                              ptrs=torch.tensor(ptrs, dtype=torch.int64).to(dev),
                              numel=torch.tensor(numel, dtype=torch.int64).to(dev), total=int(sum(numel)),
                              partial=torch.empty(h.lib.tadmm_penalty_scratch_doubles(), dtype=torch.float64,
@@ -228,23 +238,38 @@ class ADMM:
         pen = self._pen
         # pointers of z may be unchanged (in-place update) but re-check u/z identity cheaply
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        # fresh gradient storage per forward: two penalties alive in one step (or a changed rho) keep their own
+        flat = torch.empty(pen["gbytes"], dtype=torch.uint8, device=dev)
+        torch.add(pen["goff_dev"], flat.data_ptr(), out=pen["ptrs"][3 * n:])
+        grads = [flat[o:o + k * 4].view(torch.float32).view(shp)
+                 for o, k, shp in zip(pen["goff"], pen["nel"], pen["shapes"])]
         h = pen["h"]
         h.check(h.lib.tadmm_penalty(h.ptr, n, pen["ptrs"].data_ptr(), pen["numel"].data_ptr(), pen["total"],
                                     float(self.rho), float(self.rho), loss.data_ptr(), pen["partial"].data_ptr(),
                                     torch.cuda.current_stream(dev).cuda_stream))
-        return loss[0], pen["grads"]
+        return loss[0], grads
 
     # ------------------------------------------------------------------ per-layer projections (numpy in/out)
     def _project_np(self, z, kind, tt_shapes, ranks):
-        w = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)).to(self.device)
-        u = torch.zeros_like(w)
-        out = torch.empty_like(w)
-        entry = dict(kind=kind, W=w, U=u, Z=out, ranks=ranks)
-        if tt_shapes is not None:
-            entry["tt_shapes"] = list(tt_shapes)
-        plan = ops.ProjectionPlan([entry])
-        plan.run(update_u=False, use_u=False)
-        return out.cpu().numpy(), plan.ranks[0]
+        # The reference-API `prune_*` methods are called layer by layer: keep one single-layer plan (with its
+        # W/U/Z staging tensors and workspace) per distinct (kind, shape, modes, ranks) instead of building and
+        # destroying a plan per call.
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        rk = tuple(ranks) if not isinstance(ranks, int) else ranks
+        key = (kind, z.shape, tuple(tt_shapes) if tt_shapes is not None else None, rk)
+        cache = self.__dict__.setdefault("_np_plans", {})
+        ent = cache.get(key)
+        if ent is None:
+            w = torch.empty(z.shape, dtype=torch.float32, device=self.device)
+            entry = dict(kind=kind, W=w, U=torch.zeros_like(w), Z=torch.empty_like(w), ranks=ranks)
+            if tt_shapes is not None:
+                entry["tt_shapes"] = list(tt_shapes)
+            if len(cache) >= 64:                      # bounded: drop the oldest entry
+                cache.pop(next(iter(cache))).get("plan").close()
+            ent = cache[key] = dict(plan=ops.ProjectionPlan([entry]), W=w, Z=entry["Z"])
+        ent["W"].copy_(torch.from_numpy(z))
+        ent["plan"].run(update_u=False, use_u=False)
+        return ent["Z"].cpu().numpy(), ent["plan"].ranks[0]
 
     def prune_conv_rank_tt(self, z, name):                                      # admm.py:91-101
         tbl = self.hp_dict.ranks[name]

@@ -163,7 +163,8 @@ def test_tucker_projection_vs_oracle_unpinned(dev):
             eye_o[ranks[1]:, ranks[1]:] = 0      # only r_in left vectors exist; the padding columns are zero
         np.testing.assert_allclose(uo_.T @ uo_, eye_o, atol=1e-5)
         np.testing.assert_allclose(ui_.T @ ui_, np.eye(ranks[1]), atol=1e-5)
-        assert all(errs[i + 1] <= errs[i] + 1e-6 for i in range(len(errs) - 1))       # HOOI is monotone
+        # (monotonicity of the HOOI error history: test_gpu_round2.py::test_hooi_error_history_is_non_increasing,
+        #  on the path that returns the real per-sweep history)
         # core identity: core = W x0 Uo^T x1 Ui^T
         c_ref = np.einsum("oi...,or,is->rs...", w.astype(np.float64), uo_.astype(np.float64), ui_.astype(np.float64))
         np.testing.assert_allclose(core.cpu().numpy(), c_ref, atol=1e-5)

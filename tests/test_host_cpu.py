@@ -96,7 +96,7 @@ def test_hp_tables_and_selector():
     assert hp.get_hp_dict("resnet50", "3", "tt", "special") is not t
     d = hp.get_hp_dict("deit_small_patch16_224", "2", "tt")
     assert isinstance(d.ranks["blocks.0.attn.qkv.weight"], tuple)    # DeiT tables are tuples (immutable)
-    assert hp.get_hp_dict("tkc_resnet32", "3").ranks["layer3.0.conv1.weight"] == [25, 23] or True
+    assert hp.get_hp_dict("tkc_resnet32", "3").ranks["layer3.0.conv1.weight"] == [32, 25]   # tk_resnet32_hp.py:95
     assert hp.get_hp_dict("svd_mobilenetv2", "2").ranks["features.4.conv.0.weight"] == 20
     assert hp.get_hp_dict("resnet50", "3", "none") is None            # dense model -> None
     assert hp.get_hp_dict("unknown_net", "2", "tt") is None
@@ -108,6 +108,26 @@ def test_hp_tables_and_selector():
     f = hp.fresh_table("tt_resnet50_hp.HyperParamsDictSpecialRatio3x")
     f.ranks["layer4.1.conv1.weight"][2] = 1
     assert hp.fresh_table("tt_resnet50_hp.HyperParamsDictSpecialRatio3x").ranks["layer4.1.conv1.weight"][2] != 1
+
+
+def test_hp_ladder_matches_reference_golden(golden_dir):
+    """G7: every rung of utils.get_hp_dict (utils.py:258-400), recorded from the reference by
+    tests/golden/make_hp_ladder.py -- returned table, None, the bare Exception or the ImportError."""
+    import json
+    import os
+    from tadmm import hp
+    gold = json.load(open(os.path.join(golden_dir, "g7_hp_ladder.json")))
+    assert len(gold) > 2500
+    for key, want in gold.items():
+        name, ratio, fmt, ttt = key.split("|")
+        try:
+            r = hp.get_hp_dict(name, ratio, fmt, ttt)
+            got = "None" if r is None else r.table
+        except ImportError:
+            got = "ImportError"
+        except Exception as e:
+            got = "Exception:" + str(e)
+        assert got == want, (key, got, want)
 
 
 def test_flop_model_matches_survey():
