@@ -1,0 +1,262 @@
+// Cholesky QR of a tall block on the fp64 matrix cores: the orthonormalisation step of the filtered
+// eigen-solver (filter.hip).  Given the Gram matrix C = Y^T Y (n x n, n <= 256) of a block image
+// YT[n][ldy] (row j = column j of Y):
+//
+//   chol_factor : C = R^T R.  One 512-thread workgroup per problem keeps all upper 16x16 tiles of C in
+//                 registers (MFMA accumulator layout) and runs the right-looking block algorithm
+//                    W_k = R_kk^{-T}  (16x16 Cholesky + triangular inverse, one wave, in LDS)
+//                    R_kj = W_k C_kj                      (panel, one MFMA tile product each)
+//                    C_ij -= R_ki^T R_kj   (k < i <= j)   (trailing update, operands from the LDS panel)
+//                 A non-positive pivot (numerically rank deficient block) sets the problem's `bad` word.
+//   chol_solve  : Q^T = R^{-T} Y^T in place, by block forward substitution.  A wave owns 16 columns of the
+//                 image and keeps the solved 16x16 tiles in registers (the D layout of one product is the
+//                 B-operand layout of the next), so it needs neither LDS nor any cross-wave traffic:
+//                    X_kb = W_kb (Y_kb - sum_{j<kb} R_j,kb^T X_j).
+// Used twice in a row ("CholQR2") the result is orthonormal to rounding for condition numbers up to ~1e7.
+#include "common.h"
+
+namespace tadmm {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kCT = 16;            // tile edge
+constexpr int kCLd = kCT + 1;      // padded leading dimension of the LDS tiles
+constexpr int kCMaxT = 16;         // n <= 256
+constexpr int kCSlots = (kCMaxT * (kCMaxT + 1) / 2 + 7) / 8;   // upper tiles per wave: 17
+
+__device__ __forceinline__ double rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);                    // ~2^-26 relative
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
+// W = L^-1 for the 16x16 SPD tile Dg = L L^T, one wave, blocked by 4 so that every rank-4 update is ONE
+// v_mfma_f64_16x16x4 on a register-resident tile:
+//   S (accumulator layout) starts as Dg; for block b: the 4x4 block S_bb is factored and inverted redundantly by
+//   every lane (M = L_bb^-1, four dependent rsqrt), the block column P = S[:, b] M^T gives columns 4b..4b+3 of L,
+//   and S -= P P^T eliminates them.  The inverse is carried along: R starts as I, X_b = M R[b, :] are rows 4b..4b+3 of
+//   W, and R -= L[:, b] X_b -- again one MFMA, whose operands (P of this lane, X of this lane) are already in place.
+// Returns false (uniformly) on a pivot <= tiny.
+__device__ __forceinline__ bool diag_inverse(const double (*Dg)[kCLd], double (*Cb)[5], double (*Wt)[kCLd],
+                                             double* __restrict__ Wg, int lane, double tiny) {
+  const int r = lane & 15, q = lane >> 4;
+  double4_t S, R;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    S[e] = Dg[q + 4 * e][r];
+    R[e] = (q + 4 * e == r) ? 1.0 : 0.0;
+  }
+  bool ok = true;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    // block column 4b..4b+3 of S -> LDS (lanes whose column r lies in the block hold it, rows q + 4e)
+    if ((r >> 2) == b) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Cb[q + 4 * e][r & 3] = S[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double s00 = Cb[4 * b][0], s10 = Cb[4 * b + 1][0], s20 = Cb[4 * b + 2][0], s30 = Cb[4 * b + 3][0];
+    const double s11 = Cb[4 * b + 1][1], s21 = Cb[4 * b + 2][1], s31 = Cb[4 * b + 3][1];
+    const double s22 = Cb[4 * b + 2][2], s32 = Cb[4 * b + 3][2], s33 = Cb[4 * b + 3][3];
+    const double c0 = Cb[r][0], c1 = Cb[r][1], c2 = Cb[r][2], c3 = Cb[r][3];
+    ok = ok && (s00 > tiny);
+    const double i0 = rsqrt_f64(fmax(s00, tiny));
+    const double l10 = s10 * i0, l20 = s20 * i0, l30 = s30 * i0;
+    const double t11 = s11 - l10 * l10;
+    ok = ok && (t11 > tiny);
+    const double i1 = rsqrt_f64(fmax(t11, tiny));
+    const double l21 = (s21 - l20 * l10) * i1, l31 = (s31 - l30 * l10) * i1;
+    const double t22 = s22 - l20 * l20 - l21 * l21;
+    ok = ok && (t22 > tiny);
+    const double i2 = rsqrt_f64(fmax(t22, tiny));
+    const double l32 = (s32 - l30 * l20 - l31 * l21) * i2;
+    const double t33 = s33 - l30 * l30 - l31 * l31 - l32 * l32;
+    ok = ok && (t33 > tiny);
+    const double i3 = rsqrt_f64(fmax(t33, tiny));
+    // M = L_bb^-1 (lower)
+    const double m00 = i0, m11 = i1, m22 = i2, m33 = i3;
+    const double m10 = -l10 * m00 * i1;
+    const double m20 = -(l20 * m00 + l21 * m10) * i2, m21 = -l21 * m11 * i2;
+    const double m30 = -(l30 * m00 + l31 * m10 + l32 * m20) * i3, m31 = -(l31 * m11 + l32 * m21) * i3, m32 = -l32 * m22 * i3;
+    // P[r][q] = sum_{m <= q} S[r][4b+m] M[q][m]   (zero above the block: those rows are eliminated already)
+    const double p0 = c0 * m00, p1 = c0 * m10 + c1 * m11, p2 = c0 * m20 + c1 * m21 + c2 * m22,
+                 p3 = c0 * m30 + c1 * m31 + c2 * m32 + c3 * m33;
+    double P = q == 0 ? p0 : (q == 1 ? p1 : (q == 2 ? p2 : p3));
+    if (r < 4 * b) P = 0.0;
+    S = __builtin_amdgcn_mfma_f64_16x16x4f64(-P, P, S, 0, 0, 0);
+    // rows 4b..4b+3 of W: X[4b+q][r] = sum_m M[q][m] R[4b+m][r]; R[4b+m][r] is register b of lane (r, m)
+    // (rows 4b..4b+3 of R are exchanged through the rows of Wt they are about to define)
+    Wt[4 * b + q][r] = R[b];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double r0 = Wt[4 * b][r], r1 = Wt[4 * b + 1][r], r2 = Wt[4 * b + 2][r], r3 = Wt[4 * b + 3][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double x0 = m00 * r0, x1 = m10 * r0 + m11 * r1, x2 = m20 * r0 + m21 * r1 + m22 * r2,
+                 x3 = m30 * r0 + m31 * r1 + m32 * r2 + m33 * r3;
+    const double X = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+    Wt[4 * b + q][r] = X;
+    Wg[(4 * b + q) * kCT + r] = X;
+    R = __builtin_amdgcn_mfma_f64_16x16x4f64(-P, X, R, 0, 0, 0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return ok;
+}
+
+__global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __restrict__ descs) {
+  __shared__ double Dg[kCT][kCLd];
+  __shared__ double Wt[kCT][kCLd];
+  __shared__ double Cb[kCT][5];        // current 16x4 block column of the diagonal tile's Schur complement
+  __shared__ double Pn[kCMaxT][kCT][kCLd];
+  __shared__ unsigned char ti[kCMaxT * (kCMaxT + 1) / 2], tj[kCMaxT * (kCMaxT + 1) / 2];
+  __shared__ int fail;
+  const CholDesc d = descs[blockIdx.x];
+  if (d.gate && *d.gate < d.gate_min) return;
+  if (*d.bad) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: the per-slot tests below become branches
+  const int r = lane & 15, q = lane >> 4;
+  const int nbt = d.n / kCT;
+  const int ntile = nbt * (nbt + 1) / 2;
+  for (int t = tid; t < ntile; t += 512) {
+    int i = 0, rem = t, rowlen = nbt;
+    while (rem >= rowlen) { rem -= rowlen; ++i; --rowlen; }
+    ti[t] = (unsigned char)i; tj[t] = (unsigned char)(i + rem);
+  }
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  double4_t acc[kCSlots];
+  double scale = 0.0;                   // largest diagonal entry of C: pivots are judged relative to it
+#pragma unroll
+  for (int s = 0; s < kCSlots; ++s) {
+    const int t = 8 * s + wave;
+    acc[s] = double4_t{0, 0, 0, 0};
+    if (t < ntile) {
+      const int i = __builtin_amdgcn_readfirstlane(ti[t]), j = __builtin_amdgcn_readfirstlane(tj[t]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s][e] = d.C[(int64_t)(kCT * i + q + 4 * e) * d.ldc + kCT * j + r];
+    }
+  }
+  for (int i = tid; i < d.n; i += 512) scale = fmax(scale, d.C[(int64_t)i * d.ldc + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) scale = fmax(scale, __shfl_xor(scale, o, 64));
+  if (lane == 0) Pn[0][0][wave] = scale;
+  __syncthreads();
+  scale = 0.0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) scale = fmax(scale, Pn[0][0][w]);
+  const double tiny = scale * 1e-15;    // a pivot this small relative to the largest norm: numerically rank deficient
+  __syncthreads();
+
+  for (int k = 0; k < nbt; ++k) {
+    const int tkk = k * nbt - (k * (k - 1)) / 2;
+    // ---- 1. diagonal tile to LDS ----
+#pragma unroll
+    for (int s = 0; s < kCSlots; ++s)
+      if (8 * s + wave == tkk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Dg[q + 4 * e][r] = acc[s][e];
+      }
+    __syncthreads();
+    // ---- 2. W = L^-1 where Dg = L L^T, by wave 0 on the matrix cores in 4x4 blocks (see diag_inverse) ----
+    if (wave == 0) {
+      if (!diag_inverse(Dg, Cb, Wt, d.Wd + (int64_t)k * (kCT * kCT), lane, tiny) && lane == 0) fail = 1;
+    }
+    __syncthreads();
+    if (fail) { if (tid == 0) *d.bad = 1; return; }
+    // ---- 3. panel R_kj = W C_kj (j > k) ----
+    {
+      double wa[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wa[e] = Wt[r][q + 4 * e];
+#pragma unroll
+      for (int s = 0; s < kCSlots; ++s) {
+        const int t = 8 * s + wave;
+        const int pi = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
+        const int pj = t < ntile ? __builtin_amdgcn_readfirstlane(tj[t]) : -1;
+        if (pi == k && pj > k) {
+          double4_t o = {0, 0, 0, 0};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[e], acc[s][e], o, 0, 0, 0);
+          acc[s] = o;
+          const int j = pj;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            Pn[j][q + 4 * e][r] = o[e];
+            d.R[(int64_t)(kCT * k + q + 4 * e) * d.ldr + kCT * j + r] = o[e];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    // ---- 4. trailing update C_ij -= R_ki^T R_kj ----
+#pragma unroll
+    for (int s = 0; s < kCSlots; ++s) {
+      const int t = 8 * s + wave;
+      const int i = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
+      if (i > k) {
+        const int j = __builtin_amdgcn_readfirstlane(tj[t]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[i][q + 4 * e][r], Pn[j][q + 4 * e][r], acc[s], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the operand loads of one slot from being hoisted over the others
+    }
+    // (the next step's barriers order its LDS writes behind these reads)
+  }
+}
+
+void launch_chol_factor(const CholDesc* descs_dev, int nprob, hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(chol_factor_kernel, dim3(nprob), dim3(512), 0, s, descs_dev);
+}
+
+__global__ __launch_bounds__(256) void chol_solve_kernel(const CholDesc* __restrict__ descs,
+                                                         const BlockRef* __restrict__ map) {
+  const BlockRef br = map[blockIdx.x];
+  const CholDesc d = descs[br.prob];
+  if (d.gate && *d.gate < d.gate_min) return;
+  if (*d.bad) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int nbt = d.n / kCT;
+  int ring = d.rot ? *d.rot + d.sel : d.sel;
+  ring -= (ring >= 3) ? 3 : 0;
+  ring -= (ring >= 3) ? 3 : 0;
+  if (d.rot_out && br.local == 0 && threadIdx.x == 0) *d.rot_out = ring;
+  double* __restrict__ Y = ring == 0 ? d.ring[0] : (ring == 1 ? d.ring[1] : d.ring[2]);
+  if (br.local * 64 + wave * 16 >= d.ncols) return;      // ncols is a multiple of 16: whole waves drop out
+  const int col = br.local * 64 + wave * 16 + r;
+  const int64_t ldy = d.ldy;
+  double4_t X[kCMaxT];
+#pragma unroll
+  for (int kb = 0; kb < kCMaxT; ++kb) {
+    if (kb < nbt) {
+      double4_t acc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col];
+#pragma unroll
+      for (int j = 0; j < kb; ++j) {
+        // A[m][kk] = R[16j + kk][16kb + m], kk = q + 4e (the k order of the D-layout B operand X[j])
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-d.R[(int64_t)(kCT * j + q + 4 * e) * d.ldr + kCT * kb + r], X[j][e],
+                                                     acc, 0, 0, 0);
+      }
+      double4_t o = {0, 0, 0, 0};
+      const double* W = d.Wd + (int64_t)kb * (kCT * kCT);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f64_16x16x4f64(W[r * kCT + q + 4 * e], acc[e], o, 0, 0, 0);
+      X[kb] = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col] = o[e];
+    }
+  }
+}
+
+void launch_chol_solve(const CholDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(chol_solve_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+}
+
+}  // namespace tadmm

@@ -127,6 +127,90 @@ void launch_gemm_one(const GemmDesc& d, hipStream_t s);   // descriptor passed a
 void launch_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
                          int64_t ldc, const float* bias_n, hipStream_t s);
 
+// ---------------------------------------------------------------- grouped GEMM (fp64 MFMA) -- filtered eigen-solver
+// See dgemm.hip.  M, N multiples of 32, K multiple of 16; every leading dimension even (16-byte rows).
+struct DgemmDesc {
+  const double* A; const double* B; const double* C;     // explicit operands (used when the selector is < 0)
+  const double* P; const double* Q;                       // epilogue operands, shaped like C
+  double* ring[3];                                        // ring of block images, addressed as (*rot + sel) % 3
+  const int32_t* rot;                                     // device word: ring index of the current basis (nullable)
+  int32_t selA, selB, selC, selP, selQ;                   // ring offsets, or -1 = explicit pointer
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t tiles_m, tiles_n;
+  int32_t mode;                                           // epilogue, see dgemm.hip
+  const double* coef;                                     // mode 1: s0, s1, s2 (device)
+  const double* theta;                                    // mode 3: per-row shift
+  double* rowpart;                                        // modes 2, 3: [tiles_n][M] fixed-order row partials
+  const int32_t* gate; int32_t gate_min;                  // no-op unless *gate >= gate_min (gate nullable)
+};
+void launch_dgemm(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, bool b_transposed, hipStream_t s);
+// C <- coef[0]*C + coef[1]*P over M x ldc elements; block map: local = chunk of 1024 elements
+void launch_daxpby(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+
+// ---------------------------------------------------------------- Cholesky QR of a block (chol.hip)
+// C = R^T R of an n x n Gram matrix (n multiple of 16, <= 256), one workgroup per problem, upper tiles resident in
+// registers; writes the off-diagonal tiles of R and the inverses Wd[k] = R_kk^{-T} of the diagonal tiles, which
+// is what the block forward substitution Q^T = R^{-T} Y^T (chol_solve) consumes.
+struct CholDesc {
+  const double* C; int32_t ldc;         // Gram matrix (symmetric; only the upper tiles are read)
+  int32_t n;
+  double* R; int32_t ldr;               // upper factor, off-diagonal tiles only are meaningful
+  double* Wd;                           // [n/16][16*16] row-major inverse-transposed diagonal tiles
+  double* ring[3]; const int32_t* rot; int32_t sel;   // block image Y^T [n][ldy] to be solved in place
+  int32_t ldy, ncols;                   // ncols multiple of 16 (a wave of chol_solve owns 16 columns)
+  int32_t* bad;                         // set to 1 on a non-positive pivot (sticky, device word)
+  const int32_t* gate; int32_t gate_min;
+  int32_t* rot_out;                     // optional: *rot_out <- (*rot + sel) % 3 after the solve (new basis index)
+};
+void launch_chol_factor(const CholDesc* descs_dev, int nprob, hipStream_t s);
+void launch_chol_solve(const CholDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+
+// ---------------------------------------------------------------- filtered eigen-solver (filter.hip)
+// Device-resident state of one filtered problem: the stage logic runs on the device (filt_plan_kernel), launches
+// read their gates / ring indices / Chebyshev scalars from here, the host only learns "anyone still filtering?".
+struct FiltState {
+  int32_t base, res;          // ring index of the current basis Q / of the block the coming CholQR works on
+  int32_t nsteps;             // recurrence steps of the current stage (0: none)
+  int32_t active;             // 1 while another stage is wanted
+  int32_t alive;              // 0 once the problem has been handed to the fallback solver
+  int32_t bad;                // sticky failure word (pivot breakdown, degenerate bounds, failed verification)
+  int32_t stage, pad;
+  double logamp;              // accumulated log-amplification of the boundary Ritz vector relative to the damped part
+  double coef1[2];            // first step of a stage:  Y1 = coef1[0]*T + coef1[1]*Q           (T = G Q)
+  double coefk[3];            // later steps: Y_{k+1} = coefk[0]*G*Y_k + coefk[1]*Y_k + coefk[2]*Y_{k-1}
+  double b, lr, l1;           // bounds used by the last stage (diagnostics)
+  double crit;                // verification figure: bound on ||sin Theta||_F of the accepted subspace
+};
+struct FiltProb {
+  FiltState* st;
+  double* ring[3];            // block images [rp][ldy]
+  int32_t N, Npad, rp, r, r32;
+  int32_t ldy;
+  const double* rqpart; int32_t rq_tiles;   // [rq_tiles][rp] Rayleigh-quotient partials of the current basis
+  const double* vpart; int32_t v_tiles;     // [v_tiles][r32] residual partials of the Ritz pairs
+  const double* lam; const int32_t* order;  // Ritz values of the Rayleigh-Ritz solve (unsorted) and their order
+  double* sigma;                            // [r] sqrt of the kept Ritz values, descending (shared with the full path)
+  double* theta;                            // [r32] kept Ritz values (0 beyond r)
+  const double* UT;                         // [r32][ldy] Ritz vectors as rows
+  int32_t mode, ldo;                        // output convention of EigDesc
+  float* out_a; float* out_b;
+  int32_t* skip_slot;                       // word of the eig group's skip array that belongs to this problem
+  int32_t* fb_skip;                         // word of the fallback group's skip array: 1 = filtered result accepted
+};
+struct FiltParams {
+  int32_t max_degree;         // recurrence steps per stage (D)
+  double log_target;          // ln(2/eps): wanted total log-amplification
+  double cond_max;            // largest tolerated growth of the block's condition number per stage
+  double sin_tol;             // acceptance threshold of the verification
+};
+void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s);
+void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int* verdict_pinned, hipStream_t s);
+void launch_filt_flags(const FiltProb* probs_dev, int nprob, hipStream_t s);
+void launch_filt_theta(const FiltProb* probs_dev, int nprob, hipStream_t s);
+void launch_filt_verdict(const FiltProb* probs_dev, int nprob, FiltParams prm, int* verdict_pinned, hipStream_t s);
+void launch_filt_emit(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+
 // ---------------------------------------------------------------- penalty
 constexpr int kPenaltyBlocks = 1024;
 void launch_penalty(int n, const void* const* ptrs_dev, const int64_t* numel_dev, int64_t total, float rho,

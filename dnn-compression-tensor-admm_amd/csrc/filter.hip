@@ -1,0 +1,255 @@
+// Filtered eigen-solver: the leading r eigenvectors of a Gram matrix G (N x N, fp64) without a full
+// eigen-decomposition.  Replaces, for unfoldings whose kept rank is a fraction of N, the full block-Jacobi solve
+// behind numpy.linalg.svd (reference ttd.py:17) by
+//
+//   Chebyshev-filtered subspace iteration on a block of r' ~ 1.55 r vectors   (dgemm.hip: products with G)
+//   + Cholesky QR between filter stages                                        (chol.hip)
+//   + ONE Rayleigh-Ritz solve of the r' x r' projection  H = Q^T G Q           (jacobi.hip, the same kernels)
+//   + a posteriori verification of the Ritz pairs                              (residuals over spectral gaps)
+//
+// so that the latency-bound Jacobi tournament runs over r'/16 instead of N/16 super-blocks.  Everything that
+// decides the course of the iteration lives on the device:
+//   * filter bounds come from the sorted Rayleigh quotients of the current (Cholesky-ordered) basis columns:
+//     damped interval [0, b], b = smallest quotient; the r-th largest estimates lambda_r;
+//   * the degree of a stage is limited by the growth it causes in the block's condition number (Cholesky QR
+//     must stay safe) and by what is still needed: log-amplification of the boundary vector is tracked and the
+//     filter stops at ln(2/eps);
+//   * any anomaly -- pivot breakdown (numerically rank-deficient block, e.g. an exactly low-rank input),
+//     degenerate bounds, or a failed verification -- marks the problem `bad`; the host then runs the full
+//     Jacobi solve for it (the path of round 1), so results never depend on the filter being applicable.
+// The host only launches; it reads one word per problem and stage ("more filtering wanted?") and one after
+// the verification.
+#include "common.h"
+
+namespace tadmm {
+
+__device__ __forceinline__ double hash_unit(uint32_t a, uint32_t b) {
+  // splitmix-style integer hash -> uniform in (-1, 1); fixed function of (problem, element): deterministic runs
+  uint64_t x = ((uint64_t)a << 32) ^ (uint64_t)b;
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (double)(int64_t)(x >> 11) * (1.0 / 4503599627370496.0) - 1.0;    // 53 bits -> [0,2) - 1
+}
+
+// start block: ring[0][j][i] random for j < rp, i < N (zero in the padding); state reset
+__global__ __launch_bounds__(256) void filt_init_kernel(const FiltProb* __restrict__ probs,
+                                                        const BlockRef* __restrict__ map) {
+  const BlockRef br = map[blockIdx.x];
+  const FiltProb p = probs[br.prob];
+  if (br.local == 0 && threadIdx.x == 0) {
+    FiltState* st = p.st;
+    st->base = 0; st->res = 1; st->nsteps = 0; st->active = 1; st->alive = 1; st->bad = 0; st->stage = 0;
+    st->logamp = 0.0; st->crit = 0.0; st->b = st->lr = st->l1 = 0.0;
+    *p.skip_slot = 0;
+    *p.fb_skip = 0;
+  }
+  const int64_t total = (int64_t)p.rp * p.ldy;
+  const int64_t i0 = ((int64_t)br.local * 256 + threadIdx.x) * 4;
+  double* Y = p.ring[0];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = i0 + u;
+    if (i < total) {
+      const int col = (int)(i % p.ldy);
+      Y[i] = col < p.N ? hash_unit((uint32_t)br.prob * 2654435761u + 17u, (uint32_t)i) : 0.0;
+    }
+  }
+}
+
+__device__ __forceinline__ double acosh_pos(double x) { return log(x + sqrt(fmax(x * x - 1.0, 0.0))); }
+
+// One workgroup per problem, after the product T = G Q of a stage (whose epilogue left the Rayleigh-quotient
+// partials): bounds, degree and scalars of the stage.
+__global__ __launch_bounds__(256) void filt_plan_kernel(const FiltProb* __restrict__ probs, FiltParams prm,
+                                                        int last_stage, int* __restrict__ verdict) {
+  __shared__ double rho[256], sorted[256];
+  const FiltProb p = probs[blockIdx.x];
+  FiltState* st = p.st;
+  const int tid = threadIdx.x;
+  if (st->bad || !st->active) {              // uniform: read before anybody writes
+    __syncthreads();
+    if (tid == 0) {
+      st->nsteps = 0; st->res = st->base; st->active = 0;
+      if (st->bad) { st->alive = 0; *p.skip_slot = 1; }
+      verdict[1 + blockIdx.x] = 0;
+    }
+    return;
+  }
+  const int rp = p.rp;
+  for (int j = tid; j < rp; j += 256) {
+    double v = 0.0;
+    for (int t = 0; t < p.rq_tiles; ++t) v += p.rqpart[(int64_t)t * rp + j];
+    rho[j] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < rp; j += 256) {
+    const double v = rho[j];
+    int rank = 0;
+    for (int i = 0; i < rp; ++i) {
+      const double w = rho[i];
+      rank += (w > v) || (w == v && i < j);
+    }
+    sorted[rank] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double l1 = sorted[0], lr = sorted[p.r - 1], b = sorted[rp - 1];
+    bool ok = isfinite(l1) && isfinite(b) && b > 0.0 && lr > b * (1.0 + 1e-9) && l1 >= lr;
+    int m = 0;
+    if (ok) {
+      const double e = 0.5 * b, c = 0.5 * b;             // damped interval [0, b]
+      const double xr = (lr - c) / e, x1 = (l1 - c) / e;
+      const double ar = acosh_pos(xr), a1 = acosh_pos(x1);
+      const double need = prm.log_target - st->logamp;
+      if (need > 0.0) {
+        const double ln2 = 0.6931471805599453;
+        int mc = (int)floor(log(2.0 * prm.cond_max) / a1);
+        mc = max(1, mc);
+        int mn = (int)ceil((need + ln2) / ar);
+        mn = max(1, mn);
+        m = min(prm.max_degree, min(mc, mn));
+        st->logamp += m * ar - ln2;
+        st->coef1[0] = 1.0 / e; st->coef1[1] = -c / e;
+        st->coefk[0] = 2.0 / e; st->coefk[1] = -2.0 * c / e; st->coefk[2] = -1.0;
+      }
+      st->b = b; st->lr = lr; st->l1 = l1;
+    } else {
+      st->bad = 1; st->alive = 0; *p.skip_slot = 1;
+    }
+    st->nsteps = m;
+    int res = st->base + m;
+    res -= (res >= 3) ? 3 : 0; res -= (res >= 3) ? 3 : 0; res -= (res >= 3) ? 3 : 0;
+    st->res = res % 3;
+    st->active = (m > 0 && !last_stage) ? 1 : 0;
+    st->stage += 1;
+    verdict[1 + blockIdx.x] = m > 0 ? 1 : 0;
+  }
+}
+
+// after the polishing CholQR: fold late failures into the gates (alive / skip) before the Rayleigh-Ritz solve
+__global__ void filt_flags_kernel(const FiltProb* __restrict__ probs, int nprob) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nprob) return;
+  const FiltProb p = probs[q];
+  if (p.st->bad) { p.st->alive = 0; *p.skip_slot = 1; }
+}
+
+__global__ __launch_bounds__(256) void filt_theta_kernel(const FiltProb* __restrict__ probs) {
+  const FiltProb p = probs[blockIdx.x];
+  if (p.st->bad) return;
+  for (int c = threadIdx.x; c < p.r32; c += 256) {
+    const double s = c < p.r ? p.sigma[c] : 0.0;
+    p.theta[c] = s * s;
+  }
+}
+
+// Acceptance test.  For a Ritz pair (theta_c, u_c) with residual r_c the part of u_c outside the invariant subspace
+// of the eigenvalues above lambda_{r+1} is at most ||r_c|| / (theta_c - lambda_{r+1}); summed over the kept pairs
+// this bounds ||sin Theta||_F of the accepted subspace.  lambda_{r+1} is taken from the (r+1)-th Ritz value.
+__global__ __launch_bounds__(256) void filt_verdict_kernel(const FiltProb* __restrict__ probs, FiltParams prm,
+                                                           int* __restrict__ verdict) {
+  __shared__ double part[256];
+  const FiltProb p = probs[blockIdx.x];
+  FiltState* st = p.st;
+  const int tid = threadIdx.x;
+  if (st->bad) {
+    if (tid == 0) { verdict[1 + blockIdx.x] = 0; *p.fb_skip = 0; }
+    return;
+  }
+  const double th_next = p.lam[p.order[p.r]];
+  double acc = 0.0;
+  for (int c = tid; c < p.r; c += 256) {
+    double rn = 0.0;
+    for (int t = 0; t < p.v_tiles; ++t) rn += p.vpart[(int64_t)t * p.r32 + c];
+    const double gap = p.theta[c] - th_next;
+    acc += (gap > 0.0) ? rn / (gap * gap) : INFINITY;
+  }
+  part[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) part[tid] += part[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double crit = sqrt(part[0]);
+    st->crit = crit;
+    const bool ok = crit <= prm.sin_tol;     // false for NaN
+    if (!ok) { st->bad = 1; st->alive = 0; }
+    *p.fb_skip = ok ? 1 : 0;
+    verdict[1 + blockIdx.x] = ok ? 1 : 0;
+  }
+}
+
+// Ritz vectors -> the outputs the projection GEMMs read (same conventions and sign rule as eig_extract_kernel)
+__global__ __launch_bounds__(256) void filt_emit_kernel(const FiltProb* __restrict__ probs,
+                                                        const BlockRef* __restrict__ map) {
+  const BlockRef br = map[blockIdx.x];
+  const FiltProb p = probs[br.prob];
+  if (p.st->bad) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = br.local * 4 + wave;
+  if (c >= p.r) return;
+  const double* row = p.UT + (int64_t)c * p.ldy;
+  const int N = p.N;
+  double best = -1.0; int besti = 0;
+  double nrm = 0.0;
+  for (int i = lane; i < N; i += 64) {
+    const double v = row[i], a = fabs(v);
+    nrm += v * v;
+    if (a > best) { best = a; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_down(best, o, 64);
+    const int oi = __shfl_down(besti, o, 64);
+    nrm += __shfl_xor(nrm, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  besti = __shfl(besti, 0, 64);
+  const double sgn = (row[besti] < 0.0) ? -1.0 : 1.0;
+  const double inv = nrm > 0.0 ? sgn / sqrt(nrm) : 0.0;
+  const double sig = p.sigma[c];
+  const double isig = sig > 0.0 ? 1.0 / sig : 0.0;
+  const int R = p.ldo ? p.ldo : p.r;
+  for (int i = lane; i < N; i += 64) {
+    const double v = row[i] * inv;
+    if (p.mode == 0) {
+      p.out_a[(int64_t)i * R + c] = (float)v;
+    } else if (p.mode == 1) {
+      p.out_a[(int64_t)i * R + c] = (float)(v * isig);
+      p.out_b[(int64_t)c * N + i] = (float)(v * sig);
+    } else if (p.mode == 3) {
+      p.out_a[(int64_t)i * R + c] = (float)(v * isig);
+    }
+  }
+}
+
+void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(filt_init_kernel, dim3(nblocks), dim3(256), 0, s, probs_dev, map_dev);
+}
+void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int* verdict_pinned,
+                      hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(filt_plan_kernel, dim3(nprob), dim3(256), 0, s, probs_dev, prm, last_stage, verdict_pinned);
+}
+void launch_filt_flags(const FiltProb* probs_dev, int nprob, hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(filt_flags_kernel, dim3((nprob + 63) / 64), dim3(64), 0, s, probs_dev, nprob);
+}
+void launch_filt_theta(const FiltProb* probs_dev, int nprob, hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(filt_theta_kernel, dim3(nprob), dim3(256), 0, s, probs_dev);
+}
+void launch_filt_verdict(const FiltProb* probs_dev, int nprob, FiltParams prm, int* verdict_pinned, hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(filt_verdict_kernel, dim3(nprob), dim3(256), 0, s, probs_dev, prm, verdict_pinned);
+}
+void launch_filt_emit(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(filt_emit_kernel, dim3(nblocks), dim3(256), 0, s, probs_dev, map_dev);
+}
+
+}  // namespace tadmm

@@ -1,0 +1,338 @@
+// Host side of the filtered eigen-solver (filter.hip): workspace layout, descriptor construction and the launch
+// sequence of one group of problems.  Used by the TT plan (plan.hip) for the eigen-problems whose kept rank is a
+// fraction of their size, and by tadmm_eigh_top_f64 (tests).
+#pragma once
+#include "host.h"
+
+namespace tadmm {
+
+// size of the iteration block for keeping r of N eigenvectors (0: not worth filtering -> full solve)
+static inline int filter_block_size(int N, int r) {
+  const char* e = getenv("TADMM_FILTER");            // 0 disables the filtered path (A/B measurements, tests)
+  if (e && !atoi(e)) return 0;
+  if (N < 192 || r < 16) return 0;
+  const int rp = (int)align_up((size_t)(1.55 * r + 0.999), 32);
+  if (rp > 256 || rp * 100 > 56 * N || rp <= r) return 0;
+  return rp;
+}
+
+struct FilterSpec {
+  int N = 0, Npad = 0, ldg = 0, r = 0, rp = 0;
+  const double* G = nullptr;        // [Npad][ldg] symmetric, zero padded (left untouched by the filter)
+  int mode = 0, ldo = 0;            // output convention (EigDesc)
+  float* out_a = nullptr; float* out_b = nullptr;
+  double* sigma = nullptr;          // [r]
+  int32_t* skip_slot = nullptr;     // device word in the skip array of the eig group that runs the Rayleigh-Ritz solve
+  int32_t* fb_skip = nullptr;       // device word in the skip array of the fallback group
+};
+
+struct FilterGroup {
+  int nf = 0;
+  int max_degree = 8;
+  size_t prob_off = 0;                       // FiltProb[nf]
+  Phase init, stage0, p1, axpby, tfinal, hform, uform, verify, emit;
+  std::vector<Phase> steps;                  // recurrence steps k = 2 .. max_degree
+  Phase gramA, gramB;                        // Gram of the block: gated on "stage ran" / on "alive"
+  size_t cholA_off = 0, cholB_off = 0;       // CholDesc[nf]
+  size_t solve_map_off = 0; int solve_blocks = 0;
+  size_t zero_off = 0, zero_bytes = 0;       // Rayleigh-Ritz images: padding must be zero (cleared at creation)
+  // statistics of the last run (host)
+  int last_stages = 0, last_bad = 0;
+};
+
+// Rayleigh-Ritz eigen-problem of filtered problem i (appended by the caller to its eig group)
+struct FilterRR { EigDesc desc; int norm_blocks; int ext_blocks; };
+
+// Lays out workspace + descriptors.  `dev(off)` turns an arena offset into a device pointer (null while sizing).
+template <class DevFn>
+static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>& specs, Arena& da, Arena& ar, DevFn dev,
+                                 HostImage* img, std::vector<FilterRR>& rr_out) {
+  const int nf = (int)specs.size();
+  fg.nf = nf;
+  rr_out.clear();
+  if (nf == 0) return;
+  if (const char* e = getenv("TADMM_FILTER_DEGREE")) fg.max_degree = std::max(2, std::min(16, atoi(e)));
+  const int D = fg.max_degree;
+  std::vector<FiltProb> probs(nf);
+  std::vector<DgemmDesc> d_stage0(nf), d_p1(nf), d_axpby(nf), d_tfinal(nf), d_hform(nf), d_uform(nf), d_verify(nf),
+      d_gramA(nf), d_gramB(nf);
+  std::vector<std::vector<DgemmDesc>> d_steps(std::max(0, D - 1), std::vector<DgemmDesc>(nf));
+  std::vector<CholDesc> cA(nf), cB(nf);
+  std::vector<BlockRef> m_init, m_stage0, m_axpby, m_hform, m_uform, m_verify, m_emit, m_gram, m_solve;
+  const size_t zero_begin = align_up(ar.off, 256);
+  std::vector<size_t> xth_off(nf), vh_offs(nf);
+  for (int i = 0; i < nf; ++i) {   // images whose padding must be zero first, contiguous: one memset clears them
+    const int ldh = (int)align_up(specs[i].rp, 128);
+    xth_off[i] = ar.take((size_t)specs[i].rp * ldh * 8);                              // Rayleigh-Ritz image
+    vh_offs[i] = ar.take(align_up(specs[i].r, 32) * (size_t)specs[i].rp * 8);         // Ritz vectors, rows >= r stay 0
+  }
+  fg.zero_off = zero_begin;
+  fg.zero_bytes = ar.off - zero_begin;
+  for (int i = 0; i < nf; ++i) {
+    const FilterSpec& sp = specs[i];
+    const int rp = sp.rp, Npad = sp.Npad, r32 = (int)align_up(sp.r, 32), ldy = Npad, ldh = (int)align_up(rp, 128);
+    const int tn = Npad / 32, tr = rp / 32;
+    size_t ring_off[3];
+    for (auto& o : ring_off) o = ar.take((size_t)rp * ldy * 8);
+    const size_t st_off = ar.take(sizeof(FiltState));
+    const size_t c_off = ar.take((size_t)rp * rp * 8);
+    const size_t r_off = ar.take((size_t)rp * rp * 8);
+    const size_t w_off = ar.take((size_t)rp * 16 * 8);
+    const size_t rq_off = ar.take((size_t)tn * rp * 8);
+    const size_t vp_off = ar.take((size_t)tn * r32 * 8);
+    const size_t vh_off = vh_offs[i];                            // Ritz vectors in the block basis, rows (zero beyond r)
+    const size_t ut_off = ar.take((size_t)r32 * ldy * 8);
+    const size_t th_off = ar.take((size_t)r32 * 8);
+    const size_t lam_off = ar.take((size_t)rp * 8);
+    const size_t ord_off = ar.take((size_t)rp * 4);
+    const size_t off_off = ar.take(3 * 8);
+    const size_t done_off = ar.take(4);
+    const size_t sblk_off = ar.take((size_t)(rp / 16) * 256 * 8);
+    FiltState* st = (FiltState*)dev(st_off);
+    double* ring[3] = {(double*)dev(ring_off[0]), (double*)dev(ring_off[1]), (double*)dev(ring_off[2])};
+
+    FiltProb& p = probs[i];
+    memset(&p, 0, sizeof p);
+    p.st = st;
+    for (int k = 0; k < 3; ++k) p.ring[k] = ring[k];
+    p.N = sp.N; p.Npad = Npad; p.rp = rp; p.r = sp.r; p.r32 = r32; p.ldy = ldy;
+    p.rqpart = (const double*)dev(rq_off); p.rq_tiles = tn;
+    p.vpart = (const double*)dev(vp_off); p.v_tiles = tn;
+    p.lam = (const double*)dev(lam_off); p.order = (const int32_t*)dev(ord_off);
+    p.sigma = sp.sigma; p.theta = (double*)dev(th_off); p.UT = (const double*)dev(ut_off);
+    p.mode = sp.mode; p.ldo = sp.ldo; p.out_a = sp.out_a; p.out_b = sp.out_b;
+    p.skip_slot = sp.skip_slot; p.fb_skip = sp.fb_skip;
+
+    auto base_desc = [&](int M, int N_, int K) {
+      DgemmDesc g;
+      memset(&g, 0, sizeof g);
+      for (int k = 0; k < 3; ++k) g.ring[k] = ring[k];
+      g.selA = g.selB = g.selC = g.selP = g.selQ = -1;
+      g.M = M; g.N = N_; g.K = K;
+      g.tiles_m = M / 32; g.tiles_n = N_ / 32;
+      return g;
+    };
+    const int32_t* w_base = st ? &st->base : nullptr;
+    const int32_t* w_res = st ? &st->res : nullptr;
+    const int32_t* w_nsteps = st ? &st->nsteps : nullptr;
+    const int32_t* w_active = st ? &st->active : nullptr;
+    const int32_t* w_alive = st ? &st->alive : nullptr;
+    // stage 0: ring[1] = G * ring[0]        (block images are [rp][ldy]: C[j][i] = sum_k Y[j][k] G[i][k])
+    {
+      DgemmDesc g = base_desc(rp, Npad, Npad);
+      g.rot = w_base; g.selA = 0; g.selC = 1; g.B = sp.G;
+      g.lda = ldy; g.ldb = sp.ldg; g.ldc = ldy; g.mode = 0;
+      d_stage0[i] = g;
+    }
+    // first product of a stage: T = G Q  + Rayleigh quotients
+    {
+      DgemmDesc g = base_desc(rp, Npad, Npad);
+      g.rot = w_base; g.selA = 0; g.selC = 1; g.selP = 0; g.B = sp.G;
+      g.lda = ldy; g.ldb = sp.ldg; g.ldc = ldy; g.mode = 2; g.rowpart = (double*)dev(rq_off);
+      g.gate = w_active; g.gate_min = 1;
+      d_p1[i] = g;
+    }
+    {   // Y1 = coef1[0]*T + coef1[1]*Q in place of T
+      DgemmDesc g = base_desc(rp, Npad, Npad);
+      g.rot = w_base; g.selC = 1; g.selP = 0; g.ldc = ldy;
+      g.coef = st ? st->coef1 : nullptr; g.gate = w_nsteps; g.gate_min = 1;
+      d_axpby[i] = g;
+    }
+    for (int k = 2; k <= D; ++k) {     // Y_k = c0*G*Y_{k-1} + c1*Y_{k-1} + c2*Y_{k-2}, Y_j in ring[(base + j) % 3]
+      DgemmDesc g = base_desc(rp, Npad, Npad);
+      g.rot = w_base; g.selA = (k - 1) % 3; g.selP = (k - 1) % 3; g.selQ = (k - 2) % 3; g.selC = k % 3; g.B = sp.G;
+      g.lda = ldy; g.ldb = sp.ldg; g.ldc = ldy; g.mode = 1;
+      g.coef = st ? st->coefk : nullptr; g.gate = w_nsteps; g.gate_min = k;
+      d_steps[k - 2][i] = g;
+    }
+    // Gram of the block that is about to be orthonormalised: C = Y^T Y
+    {
+      DgemmDesc g = base_desc(rp, rp, Npad);
+      g.rot = w_res; g.selA = 0; g.selB = 0; g.C = (const double*)dev(c_off);
+      g.lda = ldy; g.ldb = ldy; g.ldc = rp; g.mode = 0;
+      g.gate = w_nsteps; g.gate_min = 1;
+      d_gramA[i] = g;
+      g.gate = w_alive; g.gate_min = 1;
+      d_gramB[i] = g;
+    }
+    {
+      CholDesc c;
+      memset(&c, 0, sizeof c);
+      c.C = (const double*)dev(c_off); c.ldc = rp; c.n = rp;
+      c.R = (double*)dev(r_off); c.ldr = rp; c.Wd = (double*)dev(w_off);
+      for (int k = 0; k < 3; ++k) c.ring[k] = ring[k];
+      c.rot = w_res; c.sel = 0; c.ldy = ldy; c.ncols = Npad;
+      c.bad = st ? &st->bad : nullptr;
+      c.rot_out = st ? &st->base : nullptr;
+      c.gate = w_nsteps; c.gate_min = 1;
+      cA[i] = c;
+      c.gate = w_alive; c.gate_min = 1;
+      cB[i] = c;
+    }
+    {   // T = G Q (after the polish), then H = Q^T T
+      DgemmDesc g = base_desc(rp, Npad, Npad);
+      g.rot = w_base; g.selA = 0; g.selC = 1; g.B = sp.G;
+      g.lda = ldy; g.ldb = sp.ldg; g.ldc = ldy; g.mode = 0; g.gate = w_alive; g.gate_min = 1;
+      d_tfinal[i] = g;
+      DgemmDesc hgm = base_desc(rp, rp, Npad);
+      hgm.rot = w_base; hgm.selA = 0; hgm.selB = 1; hgm.C = (const double*)dev(xth_off[i]);
+      hgm.lda = ldy; hgm.ldb = ldy; hgm.ldc = ldh; hgm.mode = 0; hgm.gate = w_alive; hgm.gate_min = 1;
+      d_hform[i] = hgm;
+    }
+    {   // U^T[c][i] = sum_k VH^T[c][k] Q^T[k][i]   (NN), then residuals of the Ritz pairs
+      DgemmDesc g = base_desc(r32, Npad, rp);
+      g.rot = w_base; g.A = (const double*)dev(vh_off); g.selB = 0; g.C = (const double*)dev(ut_off);
+      g.lda = rp; g.ldb = ldy; g.ldc = ldy; g.mode = 0; g.gate = w_alive; g.gate_min = 1;
+      d_uform[i] = g;
+      DgemmDesc v = base_desc(r32, Npad, Npad);
+      v.A = (const double*)dev(ut_off); v.B = sp.G; v.P = (const double*)dev(ut_off);
+      v.lda = ldy; v.ldb = sp.ldg; v.ldc = ldy; v.mode = 3; v.theta = (const double*)dev(th_off);
+      v.rowpart = (double*)dev(vp_off); v.gate = w_alive; v.gate_min = 1;
+      d_verify[i] = v;
+    }
+    // Rayleigh-Ritz eigen-problem
+    FilterRR rr;
+    memset(&rr, 0, sizeof rr);
+    EigDesc& e = rr.desc;
+    e.XT = (double*)dev(xth_off[i]);
+    e.N = rp; e.Npad = rp; e.ld = ldh; e.nb = rp / kJB;
+    e.off = (double*)dev(off_off); e.done = (int32_t*)dev(done_off);
+    e.lam = (double*)dev(lam_off); e.order = (int32_t*)dev(ord_off); e.sigma = sp.sigma;
+    e.r = sp.r; e.mode = 2; e.evec_out = (double*)dev(vh_off); e.sblk = (double*)dev(sblk_off);
+    rr.norm_blocks = (rp + 3) / 4; rr.ext_blocks = (sp.r + 3) / 4;
+    rr_out.push_back(rr);
+    // block maps
+    const int el_blocks = (int)(((size_t)rp * ldy + 1023) / 1024);
+    for (int b = 0; b < el_blocks; ++b) { m_init.push_back(BlockRef{i, b}); m_axpby.push_back(BlockRef{i, b}); }
+    for (int b = 0; b < tr * tn; ++b) m_stage0.push_back(BlockRef{i, b});
+    for (int b = 0; b < tr * tr; ++b) { m_gram.push_back(BlockRef{i, b}); m_hform.push_back(BlockRef{i, b}); }
+    for (int b = 0; b < (r32 / 32) * tn; ++b) { m_uform.push_back(BlockRef{i, b}); m_verify.push_back(BlockRef{i, b}); }
+    for (int b = 0; b < (sp.r + 3) / 4; ++b) m_emit.push_back(BlockRef{i, b});
+    for (int b = 0; b < (int)align_up(Npad, 64) / 64; ++b) m_solve.push_back(BlockRef{i, b});
+    (void)vh_off;
+  }
+  fg.prob_off = da.take(probs.size() * sizeof(FiltProb));
+  if (img) img->put(fg.prob_off, probs.data(), probs.size() * sizeof(FiltProb));
+  auto place = [&](Phase& ph, const std::vector<DgemmDesc>& d, const std::vector<BlockRef>& m) {
+    place_phase(ph, da, img, d.data(), d.size() * sizeof(DgemmDesc), nf, m);
+  };
+  place(fg.stage0, d_stage0, m_stage0);
+  place(fg.p1, d_p1, m_stage0);
+  place(fg.axpby, d_axpby, m_axpby);
+  fg.steps.assign(d_steps.size(), Phase());
+  for (size_t k = 0; k < d_steps.size(); ++k) place(fg.steps[k], d_steps[k], m_stage0);
+  place(fg.gramA, d_gramA, m_gram);
+  place(fg.gramB, d_gramB, m_gram);
+  place(fg.tfinal, d_tfinal, m_stage0);
+  place(fg.hform, d_hform, m_hform);
+  place(fg.uform, d_uform, m_uform);
+  place(fg.verify, d_verify, m_verify);
+  fg.cholA_off = da.take(cA.size() * sizeof(CholDesc));
+  fg.cholB_off = da.take(cB.size() * sizeof(CholDesc));
+  fg.solve_map_off = da.take(m_solve.size() * sizeof(BlockRef));
+  fg.solve_blocks = (int)m_solve.size();
+  {   // init / emit phases carry no descriptor array of their own (they read FiltProb)
+    fg.init.nprob = nf; fg.init.nblocks = (int)m_init.size();
+    fg.init.map_off = da.take(m_init.size() * sizeof(BlockRef));
+    fg.emit.nprob = nf; fg.emit.nblocks = (int)m_emit.size();
+    fg.emit.map_off = da.take(std::max<size_t>(m_emit.size() * sizeof(BlockRef), 16));
+  }
+  if (img) {
+    img->put(fg.cholA_off, cA.data(), cA.size() * sizeof(CholDesc));
+    img->put(fg.cholB_off, cB.data(), cB.size() * sizeof(CholDesc));
+    img->put(fg.solve_map_off, m_solve.data(), m_solve.size() * sizeof(BlockRef));
+    img->put(fg.init.map_off, m_init.data(), m_init.size() * sizeof(BlockRef));
+    if (!m_emit.empty()) img->put(fg.emit.map_off, m_emit.data(), m_emit.size() * sizeof(BlockRef));
+  }
+}
+
+static inline FiltParams filter_params(const FilterGroup& fg) {
+  FiltParams prm;
+  prm.max_degree = fg.max_degree;
+  prm.log_target = log(2.0 / 1e-11);
+  prm.cond_max = 1e6;
+  prm.sin_tol = 5e-6;
+  if (const char* e = getenv("TADMM_FILTER_EPS")) prm.log_target = log(2.0 / atof(e));
+  if (const char* e = getenv("TADMM_FILTER_SINTOL")) prm.sin_tol = atof(e);
+  return prm;
+}
+
+// Part 1: filter + orthonormalise + form the Rayleigh-Ritz images.  One host wait per stage ("anyone still
+// filtering?", a word per problem in pinned memory).
+static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, PollCtx& poll, hipStream_t s, bool debug) {
+  if (fg.nf == 0) return TADMM_OK;
+  auto D = [&](size_t off) { return ws + off; };
+  const FiltProb* probs = (const FiltProb*)D(fg.prob_off);
+  const FiltParams prm = filter_params(fg);
+  auto gemm = [&](const Phase& ph, bool bt = true) {
+    launch_dgemm((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, bt, s);
+  };
+  auto cholqr = [&](const Phase& gram, size_t chol_off) {
+    gemm(gram);
+    launch_chol_factor((const CholDesc*)D(chol_off), fg.nf, s);
+    launch_chol_solve((const CholDesc*)D(chol_off), (const BlockRef*)D(fg.solve_map_off), fg.solve_blocks, s);
+  };
+  launch_filt_init(probs, (const BlockRef*)D(fg.init.map_off), fg.init.nblocks, fg.nf, s);
+  gemm(fg.stage0);
+  cholqr(fg.gramB, fg.cholB_off);
+  int smax = 12;
+  if (const char* e = getenv("TADMM_FILTER_STAGES")) smax = std::max(1, atoi(e));
+  int stages = 0;
+  for (int st = 0; st < smax; ++st) {
+    gemm(fg.p1);
+    launch_filt_plan(probs, fg.nf, prm, st == smax - 1, poll.host, s);
+    HIP_OK(h, hipEventRecord(poll.ev[0], s));
+    HIP_OK(h, hipEventSynchronize(poll.ev[0]));
+    bool any = false;
+    for (int q = 0; q < fg.nf; ++q) any = any || poll.host[1 + q] != 0;
+    if (!any) break;
+    ++stages;
+    launch_daxpby((const DgemmDesc*)D(fg.axpby.desc_off), (const BlockRef*)D(fg.axpby.map_off), fg.axpby.nblocks, s);
+    for (const Phase& ph : fg.steps) gemm(ph);
+    cholqr(fg.gramA, fg.cholA_off);
+  }
+  fg.last_stages = stages;
+  cholqr(fg.gramB, fg.cholB_off);        // second pass: orthonormal to rounding
+  launch_filt_flags(probs, fg.nf, s);
+  gemm(fg.tfinal);
+  gemm(fg.hform);
+  if (debug) fprintf(stderr, "[tadmm] filter: %d problems, %d stages of <= %d steps\n", fg.nf, stages, fg.max_degree);
+  return TADMM_OK;
+}
+
+// Part 2 (after the Rayleigh-Ritz solve + eig_norms/sort/extract of the group): Ritz vectors, verification, outputs.
+// Returns the number of problems that must take the fallback solve in *nbad.
+static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, PollCtx& poll, hipStream_t s, bool debug,
+                                  int* nbad) {
+  *nbad = 0;
+  if (fg.nf == 0) return TADMM_OK;
+  auto D = [&](size_t off) { return ws + off; };
+  const FiltProb* probs = (const FiltProb*)D(fg.prob_off);
+  const FiltParams prm = filter_params(fg);
+  launch_filt_theta(probs, fg.nf, s);
+  launch_dgemm((const DgemmDesc*)D(fg.uform.desc_off), (const BlockRef*)D(fg.uform.map_off), fg.uform.nblocks, false, s);
+  launch_dgemm((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, true, s);
+  launch_filt_verdict(probs, fg.nf, prm, poll.host, s);
+  launch_filt_emit(probs, (const BlockRef*)D(fg.emit.map_off), fg.emit.nblocks, s);
+  HIP_OK(h, hipEventRecord(poll.ev[0], s));
+  HIP_OK(h, hipEventSynchronize(poll.ev[0]));
+  int bad = 0;
+  for (int q = 0; q < fg.nf; ++q) bad += poll.host[1 + q] ? 0 : 1;
+  *nbad = bad;
+  fg.last_bad = bad;
+  if (debug) {
+    fprintf(stderr, "[tadmm] filter: %d of %d problems fall back to the full solve\n", bad, fg.nf);
+    std::vector<FiltProb> hp(fg.nf);
+    if (hipMemcpy(hp.data(), probs, hp.size() * sizeof(FiltProb), hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int q = 0; q < fg.nf; ++q) {
+        FiltState st;
+        if (hipMemcpy(&st, hp[q].st, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) break;
+        fprintf(stderr, "[tadmm]   filt %2d: N=%d r=%d rp=%d stages=%d logamp=%.1f crit=%.2e bad=%d b=%.4g lr=%.4g l1=%.4g\n", q,
+                hp[q].N, hp[q].r, hp[q].rp, st.stage, st.logamp, st.crit, st.bad, st.b, st.lr, st.l1);
+      }
+    }
+  }
+  return TADMM_OK;
+}
+
+}  // namespace tadmm

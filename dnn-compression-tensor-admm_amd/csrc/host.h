@@ -34,6 +34,45 @@ namespace tadmm {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+struct Phase {  // one grouped launch: descriptor array + block map inside the device arena
+  size_t desc_off = 0, map_off = 0;
+  int nprob = 0, nblocks = 0;
+};
+
+// A simple bump allocator that is run twice: once with base==nullptr to size the workspace, once for real.
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(char* b) : base(b) {}
+  size_t take(size_t bytes, size_t align = 256) {
+    off = align_up(off, align);
+    const size_t o = off;
+    off += bytes;
+    return o;
+  }
+};
+
+struct HostImage {   // host copy of the descriptor part of the arena
+  std::vector<char> bytes;
+  void put(size_t off, const void* src, size_t n) {
+    if (bytes.size() < off + n) bytes.resize(off + n);
+    memcpy(bytes.data() + off, src, n);
+  }
+};
+
+// descriptor array + block map of one grouped launch -> descriptor arena (and the host image when given)
+static inline void place_phase(Phase& ph, Arena& da, HostImage* img, const void* descs, size_t dbytes, int nprob,
+                               const std::vector<BlockRef>& map) {
+  ph.nprob = nprob;
+  ph.nblocks = (int)map.size();
+  ph.desc_off = da.take(std::max<size_t>(dbytes, 16));
+  ph.map_off = da.take(std::max<size_t>(map.size() * sizeof(BlockRef), 16));
+  if (img) {
+    if (dbytes) img->put(ph.desc_off, descs, dbytes);
+    if (!map.empty()) img->put(ph.map_off, map.data(), map.size() * sizeof(BlockRef));
+  }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH "Workgroup
 // dispatch").  Re-order a block map so that CONSECUTIVE logical blocks land on the same XCD: the tournament
 // hands a super-block from workgroup q to q+-1 between launches, so the next launch finds it in that XCD's L2.

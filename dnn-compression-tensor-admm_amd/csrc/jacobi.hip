@@ -1058,7 +1058,12 @@ __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restr
   const int c = br.local * 4 + wave;
   if (c >= d.r) return;
   const int j = d.order[c];
-  const double lam = d.lam[j];
+  double lam = d.lam[j];
+  // Numerically rank-deficient input: a column whose eigenvalue is at the rounding floor of the largest one is
+  // rounding residue -- its direction is NOT orthogonal to the genuine eigenvectors, so keeping it would count
+  // their energy twice.  Such directions carry nothing (sigma <= 1e-6 sigma_max): emit a zero vector instead
+  // (the reference's LAPACK pads with an arbitrary orthonormal completion; Z is unaffected).
+  if (lam <= 1e-12 * d.lam[d.order[0]]) lam = 0.0;
   const double* row = d.XT + (int64_t)j * d.ld;
   // deterministic sign: the entry of largest magnitude (first on ties) is made positive
   double best = -1.0; int besti = 0;

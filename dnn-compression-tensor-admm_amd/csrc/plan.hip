@@ -14,6 +14,7 @@
 // (layer, local block) through a BlockRef table built once at plan creation.  All descriptors live in
 // the caller-provided workspace; tadmm_plan_run allocates nothing.
 #include "host.h"
+#include "filter_host.h"
 
 #include <cmath>
 
@@ -128,11 +129,6 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------
-struct Phase {  // one grouped launch: descriptor array + block map inside the device arena
-  size_t desc_off = 0, map_off = 0;
-  int nprob = 0, nblocks = 0;
-};
-
 struct StepPlan {
   Phase gram_p, gram_r, eig_tick, eig_norm, eig_ext, proj;
   size_t eig_desc_off = 0;
@@ -149,6 +145,18 @@ struct StepPlan {
   size_t prev_off_dev = 0;            // [neig] doubles of the convergence kernel
   std::vector<int> nb;            // per problem
   std::vector<int> layer_of;      // problem -> layer
+  // filtered eigen-solver (filter_host.h): the problems of this level it serves keep their slot in the eig group,
+  // where their r' x r' Rayleigh-Ritz problem replaces the full N x N one; the full variants form the fallback group
+  FilterGroup fg;
+  std::vector<int> filt_of;       // filtered problem -> problem of the level
+  size_t skip_off = 0;            // [neig] ints: eig group (set for filtered problems that went bad)
+  size_t fb_skip_off = 0;         // [nf] ints: fallback group (1 = filtered result accepted)
+  struct Fallback {
+    Phase tick, self, norm, ext;
+    int neig = 0, gsteps = 0, mode = 0, ld_max = 0, npad_max = 0, last_sweeps = 0;
+    size_t tick_lds = 0, prev_off_dev = 0;
+    std::vector<int> nb;
+  } fb;
 };
 
 struct tadmm_plan_s {
@@ -176,30 +184,11 @@ struct tadmm_plan_s {
   int inner_sweeps = 1;
   bool debug = false;
   int max_global_sweeps = 40;
+  // filtered eigen-solver statistics of the last run
+  int filt_problems = 0, filt_fallbacks = 0, filt_stages = 0;
 };
 
 namespace {
-
-// A simple bump allocator that is run twice: once with base==nullptr to size the workspace, once for real.
-struct Arena {
-  char* base;
-  size_t off = 0;
-  explicit Arena(char* b) : base(b) {}
-  size_t take(size_t bytes, size_t align = 256) {
-    off = align_up(off, align);
-    const size_t o = off;
-    off += bytes;
-    return o;
-  }
-};
-
-struct HostImage {   // host copy of the descriptor part of the arena
-  std::vector<char> bytes;
-  void put(size_t off, const void* src, size_t n) {
-    if (bytes.size() < off + n) bytes.resize(off + n);
-    memcpy(bytes.data() + off, src, n);
-  }
-};
 
 struct Built {
   // per layer buffers (offsets in the arena)
@@ -327,7 +316,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     std::vector<GramDesc> gd;
     std::vector<EigDesc> ed;
     std::vector<GemmDesc> pd;
-    std::vector<BlockRef> m_gp, m_gr, m_tick, m_norm, m_ext, m_proj;
+    std::vector<BlockRef> m_gp, m_gr, m_proj;
     std::vector<int> gp_cost;     // per problem: K chunk of its Gram workgroups (longest first in the block map)
     std::vector<int> layer_of;
     for (int l = 0; l < n; ++l) {
@@ -346,7 +335,10 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     sp.off_off = ar.take((size_t)std::max(1, sp.neig) * 3 * 8);
     sp.done_off = ar.take((size_t)std::max(1, sp.neig) * 4);
     sp.prev_off_dev = ar.take((size_t)std::max(1, sp.neig) * 8);
+    sp.skip_off = ar.take((size_t)std::max(1, sp.neig) * 4);
     sp.gsteps = 0;
+    std::vector<FilterSpec> fspecs;
+    sp.filt_of.clear();
     for (int p = 0; p < sp.neig; ++p) {
       const int l = layer_of[p];
       const LayerGeom& g = P->layers[l];
@@ -406,11 +398,14 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       e.evec_out = nullptr;
       e.sblk = (double*)dev(sblk_off);
       ed.push_back(e);
-      sp.nb.push_back(st.nb);
-      sp.ld_max = std::max(sp.ld_max, st.ld);
-      sp.npad_max = std::max(sp.npad_max, st.Npad);
-      for (int b = 0; b < (st.Npad + 3) / 4; ++b) m_norm.push_back(BlockRef{p, b});
-      for (int b = 0; b < (st.r + 3) / 4; ++b) m_ext.push_back(BlockRef{p, b});
+      if (const int rp = filter_block_size(st.N, st.r)) {
+        FilterSpec fs;
+        fs.N = st.N; fs.Npad = st.Npad; fs.ldg = st.ld; fs.r = st.r; fs.rp = rp;
+        fs.G = e.XT; fs.mode = e.mode; fs.ldo = e.ldo; fs.out_a = e.out_a; fs.out_b = e.out_b; fs.sigma = e.sigma;
+        fs.skip_slot = (int32_t*)dev(sp.skip_off) + p;
+        fspecs.push_back(fs);
+        sp.filt_of.push_back(p);
+      }
       // projection GEMM
       GemmDesc pg;
       memset(&pg, 0, sizeof pg);
@@ -452,38 +447,75 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     sp.gram_r.map_off = da.take(std::max<size_t>(m_gr.size() * sizeof(BlockRef), 16));
     sp.gram_r.nblocks = (int)m_gr.size();
     if (img && !m_gr.empty()) img->put(sp.gram_r.map_off, m_gr.data(), m_gr.size() * sizeof(BlockRef));
-    // tick shape of the level: LDS-resident super-pairs when every problem fits, else plain pairs
+    // ---- filtered problems: Rayleigh-Ritz problem in the eig group, full problem in the fallback group ----
+    std::vector<EigDesc> ed_fb;
     {
-      const int want = choose_jacobi_mode(sp.ld_max);
-      sp.mode = sp.neig > 0 ? want : 0;
+      const int nf = (int)fspecs.size();
+      sp.fb_skip_off = ar.take((size_t)std::max(1, nf) * 4);
+      for (int i = 0; i < nf; ++i) fspecs[i].fb_skip = (int32_t*)dev(sp.fb_skip_off) + i;
+      std::vector<FilterRR> rr;
+      filter_layout(sp.fg, fspecs, da, ar, dev, img, rr);
+      for (int i = 0; i < nf; ++i) {
+        const int p = sp.filt_of[i];
+        ed_fb.push_back(ed[p]);
+        // the fallback problem needs convergence words of its own (the group's are used by the Rayleigh-Ritz solve)
+        ed_fb.back().off = (double*)dev(ar.take(3 * 8));
+        ed_fb.back().done = (int32_t*)dev(ar.take(4));
+        EigDesc e = rr[i].desc;
+        e.off = ed[p].off; e.done = ed[p].done;
+        ed[p] = e;
+      }
     }
-    sp.super = sp.mode >= 1;
-    sp.tick_lds = sp.mode == 1 ? jacobi_tick2_lds_bytes(sp.ld_max) : jacobi_tick_lds_bytes(sp.ld_max);
-    sp.gsteps = 0;
-    std::vector<BlockRef> m_self;
-    for (int pq = 0; pq < sp.neig; ++pq) {
-      const int units = sp.super ? sp.nb[pq] / 2 : sp.nb[pq];     // players of the tournament
-      sp.nb[pq] = units;
-      sp.gsteps = std::max(sp.gsteps, units - 1);
-      for (int b = 0; b < units / 2; ++b) m_tick.push_back(BlockRef{pq, b});
-      if (sp.mode >= 2) for (int b = 0; b < units; ++b) m_self.push_back(BlockRef{pq, b});
+    struct EigMaps { std::vector<BlockRef> tick, self, norm, ext; std::vector<int> nb; int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0; size_t tick_lds = 0; };
+    auto build_maps = [&](const std::vector<EigDesc>& descs) {
+      EigMaps m;
+      for (const EigDesc& e : descs) { m.ld_max = std::max(m.ld_max, e.ld); m.npad_max = std::max(m.npad_max, e.Npad); }
+      // tick shape of the group: LDS-resident super-pairs when every problem fits, else plain pairs
+      m.mode = descs.empty() ? 0 : choose_jacobi_mode(m.ld_max);
+      const bool super = m.mode >= 1;
+      m.tick_lds = m.mode == 1 ? jacobi_tick2_lds_bytes(m.ld_max) : jacobi_tick_lds_bytes(m.ld_max);
+      for (int pq = 0; pq < (int)descs.size(); ++pq) {
+        const EigDesc& e = descs[pq];
+        const int units = super ? e.nb / 2 : e.nb;       // players of the tournament
+        m.nb.push_back(units);
+        m.gsteps = std::max(m.gsteps, units - 1);
+        for (int b = 0; b < units / 2; ++b) m.tick.push_back(BlockRef{pq, b});
+        if (m.mode >= 2) for (int b = 0; b < units; ++b) m.self.push_back(BlockRef{pq, b});
+        for (int b = 0; b < (e.Npad + 3) / 4; ++b) m.norm.push_back(BlockRef{pq, b});
+        for (int b = 0; b < (e.r + 3) / 4; ++b) m.ext.push_back(BlockRef{pq, b});
+      }
+      xcd_group(m.tick);
+      xcd_group(m.self);
+      return m;
+    };
+    auto place_map = [&](Phase& ph, const Phase& like, const std::vector<BlockRef>& map) {
+      ph = like;
+      ph.map_off = da.take(std::max<size_t>(map.size() * sizeof(BlockRef), 16));
+      ph.nblocks = (int)map.size();
+      if (img && !map.empty()) img->put(ph.map_off, map.data(), map.size() * sizeof(BlockRef));
+    };
+    {
+      EigMaps m = build_maps(ed);
+      sp.mode = m.mode; sp.super = m.mode >= 1; sp.tick_lds = m.tick_lds; sp.gsteps = m.gsteps;
+      sp.ld_max = m.ld_max; sp.npad_max = m.npad_max; sp.nb = m.nb;
+      place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m.tick);
+      sp.eig_desc_off = sp.eig_tick.desc_off;
+      place_map(sp.eig_self, sp.eig_tick, m.self);
+      place_map(sp.eig_norm, sp.eig_tick, m.norm);
+      place_map(sp.eig_ext, sp.eig_tick, m.ext);
     }
-    xcd_group(m_tick);
-    place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m_tick);
-    sp.eig_self = sp.eig_tick;
-    xcd_group(m_self);
-    sp.eig_self.map_off = da.take(std::max<size_t>(m_self.size() * sizeof(BlockRef), 16));
-    sp.eig_self.nblocks = (int)m_self.size();
-    if (img && !m_self.empty()) img->put(sp.eig_self.map_off, m_self.data(), m_self.size() * sizeof(BlockRef));
-    sp.eig_desc_off = sp.eig_tick.desc_off;
-    sp.eig_norm = sp.eig_tick;
-    sp.eig_norm.map_off = da.take(std::max<size_t>(m_norm.size() * sizeof(BlockRef), 16));
-    sp.eig_norm.nblocks = (int)m_norm.size();
-    if (img && !m_norm.empty()) img->put(sp.eig_norm.map_off, m_norm.data(), m_norm.size() * sizeof(BlockRef));
-    sp.eig_ext = sp.eig_tick;
-    sp.eig_ext.map_off = da.take(std::max<size_t>(m_ext.size() * sizeof(BlockRef), 16));
-    sp.eig_ext.nblocks = (int)m_ext.size();
-    if (img && !m_ext.empty()) img->put(sp.eig_ext.map_off, m_ext.data(), m_ext.size() * sizeof(BlockRef));
+    {
+      EigMaps m = build_maps(ed_fb);
+      StepPlan::Fallback& fb = sp.fb;
+      fb.neig = (int)ed_fb.size();
+      fb.mode = m.mode; fb.tick_lds = m.tick_lds; fb.gsteps = m.gsteps; fb.ld_max = m.ld_max; fb.npad_max = m.npad_max;
+      fb.nb = m.nb;
+      fb.prev_off_dev = ar.take((size_t)std::max(1, fb.neig) * 8);
+      place(fb.tick, ed_fb.data(), ed_fb.size() * sizeof(EigDesc), fb.neig, m.tick);
+      place_map(fb.self, fb.tick, m.self);
+      place_map(fb.norm, fb.tick, m.norm);
+      place_map(fb.ext, fb.tick, m.ext);
+    }
     place(sp.proj, pd.data(), pd.size() * sizeof(GemmDesc), sp.neig, m_proj);
   }
 
@@ -648,6 +680,13 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
     hipError_t e = hipMemcpy(P->ws, img.bytes.data(), img.bytes.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "descriptor upload failed: %s", hipGetErrorString(e)); }
   }
+  for (const StepPlan& sp : P->steps) {      // Rayleigh-Ritz images / skip words start from zero
+    hipError_t e = hipSuccess;
+    if (sp.fg.zero_bytes) e = hipMemset(P->ws + sp.fg.zero_off, 0, sp.fg.zero_bytes);
+    if (e == hipSuccess) e = hipMemset(P->ws + sp.skip_off, 0, (size_t)std::max(1, sp.neig) * 4);
+    if (e == hipSuccess) e = hipMemset(P->ws + sp.fb_skip_off, 0, (size_t)std::max(1, sp.fg.nf) * 4);
+    if (e != hipSuccess) { delete P; CTX_FAIL(h, TADMM_ERR_HIP, "workspace clear failed: %s", hipGetErrorString(e)); }
+  }
   if (const char* e = getenv("TADMM_JACOBI_TOL")) P->tol = atof(e);
   if (getenv("TADMM_DEBUG")) P->debug = true;
   size_t maxe = 1;
@@ -685,6 +724,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
   auto D = [&](size_t off) { return ws + off; };
   double acc_ms[8] = {0};
   int total_sweeps = 0;
+  p->filt_problems = p->filt_fallbacks = p->filt_stages = 0;
   // timing helper: record a pair of events around a phase and accumulate after a sync
   auto tic = [&](int i) { if (p->timing) (void)hipEventRecord(p->ev[i], s); };
   auto toc = [&](int i, int slot) {
@@ -710,7 +750,13 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
                        sp.gram_r.nblocks, s);
     toc(0, 1);
     tic(0);
+    const bool filtered = sp.fg.nf > 0;
+    if (filtered) {
+      const int rc = filter_run_pre(h, sp.fg, ws, p->poll, s, p->debug);
+      if (rc != TADMM_OK) return rc;
+    }
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
+    const int32_t* skip = filtered ? (const int32_t*)D(sp.skip_off) : nullptr;
     EigGroup eg;
     eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode;
     eg.ld_max = sp.ld_max; eg.tick_lds = sp.tick_lds;
@@ -720,6 +766,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     eg.off_dev = (const double*)D(sp.off_off); eg.done_dev = (const int*)D(sp.done_off);
     eg.npad_max = sp.npad_max;
     eg.expected = sp.last_sweeps;
+    eg.skip = skip;
     int gs = 0;
     bool small_pending = false;
     {
@@ -729,9 +776,48 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     }
     sp.last_sweeps = gs;
     total_sweeps += gs;
-    launch_eig_norms(ed, (const BlockRef*)D(sp.eig_norm.map_off), sp.eig_norm.nblocks, s);
-    launch_eig_sort(ed, sp.neig, s);
-    launch_eig_extract(ed, (const BlockRef*)D(sp.eig_ext.map_off), sp.eig_ext.nblocks, s);
+    launch_eig_norms(ed, (const BlockRef*)D(sp.eig_norm.map_off), sp.eig_norm.nblocks, s, skip);
+    launch_eig_sort(ed, sp.neig, s, skip);
+    launch_eig_extract(ed, (const BlockRef*)D(sp.eig_ext.map_off), sp.eig_ext.nblocks, s, skip);
+    if (filtered) {
+      if (small_pending) {
+        const int rc = check_small_group(h, eg, p->poll);
+        if (rc != TADMM_OK) return rc;
+        small_pending = false;
+      }
+      int nbad = 0;
+      int rc = filter_run_post(h, sp.fg, ws, p->poll, s, p->debug, &nbad);
+      if (rc != TADMM_OK) return rc;
+      p->filt_problems += sp.fg.nf;
+      p->filt_fallbacks += nbad;
+      p->filt_stages = std::max(p->filt_stages, sp.fg.last_stages);
+      if (nbad > 0) {       // the full Jacobi solve for the problems the filter could not certify
+        StepPlan::Fallback& fb = sp.fb;
+        const EigDesc* fd = (const EigDesc*)D(fb.tick.desc_off);
+        const int32_t* fskip = (const int32_t*)D(sp.fb_skip_off);
+        EigGroup fgp;
+        fgp.ed = fd; fgp.neig = fb.neig; fgp.players = fb.nb.data(); fgp.gsteps = fb.gsteps; fgp.mode = fb.mode;
+        fgp.ld_max = fb.ld_max; fgp.tick_lds = fb.tick_lds;
+        fgp.tick_map = (const BlockRef*)D(fb.tick.map_off); fgp.tick_blocks = fb.tick.nblocks;
+        fgp.self_map = (const BlockRef*)D(fb.self.map_off); fgp.self_blocks = fb.self.nblocks;
+        fgp.prev_dev = (double*)D(fb.prev_off_dev);
+        fgp.npad_max = fb.npad_max;
+        fgp.expected = 0;
+        fgp.skip = fskip;
+        int fgs = 0;
+        bool fsmall = false;
+        rc = run_eig_group(h, fgp, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &fgs, &fsmall);
+        if (rc != TADMM_OK) return rc;
+        total_sweeps += fgs;
+        launch_eig_norms(fd, (const BlockRef*)D(fb.norm.map_off), fb.norm.nblocks, s, fskip);
+        launch_eig_sort(fd, fb.neig, s, fskip);
+        launch_eig_extract(fd, (const BlockRef*)D(fb.ext.map_off), fb.ext.nblocks, s, fskip);
+        if (fsmall) {
+          rc = check_small_group(h, fgp, p->poll);
+          if (rc != TADMM_OK) return rc;
+        }
+      }
+    }
     toc(0, 2);
     tic(0);
     launch_gemm((const GemmDesc*)D(sp.proj.desc_off), (const BlockRef*)D(sp.proj.map_off), sp.proj.nblocks, s);
@@ -767,6 +853,14 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
   hipStream_t s = (hipStream_t)stream_;
   HIP_OK(p->h, hipMemcpyAsync(out_host, p->ws + off, (size_t)g.steps[step].r * 8, hipMemcpyDeviceToHost, s));
   HIP_OK(p->h, hipStreamSynchronize(s));
+  return TADMM_OK;
+}
+
+int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]) {
+  if (!p || !out) return TADMM_ERR_INVALID;
+  int eligible = 0;
+  for (const StepPlan& sp : p->steps) eligible += sp.fg.nf;
+  out[0] = eligible; out[1] = p->filt_problems; out[2] = p->filt_fallbacks; out[3] = p->filt_stages;
   return TADMM_OK;
 }
 
@@ -1023,6 +1117,84 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   // -> evals_out[c] = lam[order[c]] via a tiny gather done with the extract's sigma: sigma^2
   //    (done by the caller-visible helper below to stay allocation-free)
   tadmm_square_copy(sigma, evals_out, N, s);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+// ---- building blocks of the filtered eigen-solver, exposed for tests ----
+size_t tadmm_dgemm_scratch_bytes(int M, int N) {
+  return align_up(sizeof(DgemmDesc), 256) + align_up((size_t)(M / 32) * (N / 32) * sizeof(BlockRef), 256);
+}
+
+int tadmm_dgemm_f64(tadmm_handle h, const double* A, const double* B, double* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, int b_transposed, void* scratch, size_t scratch_bytes, void* stream_) {
+  if (!h || !A || !B || !C || !scratch) return TADMM_ERR_INVALID;
+  if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32 || K % 16 || (lda & 1) || (ldb & 1) || (ldc & 1))
+    CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_dgemm_f64: M, N multiples of 32, K of 16, even leading dimensions");
+  if (scratch_bytes < tadmm_dgemm_scratch_bytes(M, N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "dgemm scratch too small");
+  hipStream_t s = (hipStream_t)stream_;
+  DgemmDesc g;
+  memset(&g, 0, sizeof g);
+  g.A = A; g.B = B; g.C = C; g.selA = g.selB = g.selC = g.selP = g.selQ = -1;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.tiles_m = M / 32; g.tiles_n = N / 32;
+  std::vector<BlockRef> map;
+  for (int b = 0; b < g.tiles_m * g.tiles_n; ++b) map.push_back(BlockRef{0, b});
+  DgemmDesc* gd = (DgemmDesc*)scratch;
+  BlockRef* md = (BlockRef*)((char*)scratch + align_up(sizeof(DgemmDesc), 256));
+  HIP_OK(h, hipMemcpyAsync(gd, &g, sizeof g, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(md, map.data(), map.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipStreamSynchronize(s));
+  launch_dgemm(gd, md, (int)map.size(), b_transposed != 0, s);
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+size_t tadmm_cholqr_scratch_bytes(int n, int ncols) {
+  const size_t cols64 = align_up(ncols, 64);
+  return align_up(sizeof(DgemmDesc), 256) + align_up(sizeof(CholDesc), 256) + 2 * align_up((size_t)n * n * 8, 256) +
+         align_up((size_t)n * 16 * 8, 256) + align_up((size_t)(n / 32) * (n / 32) * sizeof(BlockRef), 256) +
+         align_up((cols64 / 64) * sizeof(BlockRef), 256) + 256;
+}
+
+int tadmm_cholqr_f64(tadmm_handle h, double* YT, int n, int ncols, int ldy, void* scratch, size_t scratch_bytes,
+                     int* bad_out_host, void* stream_) {
+  if (!h || !YT || !scratch || !bad_out_host) return TADMM_ERR_INVALID;
+  if (n <= 0 || n > 256 || n % 32 || ncols <= 0 || ncols % 64 || ldy < ncols || (ldy & 1))
+    CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_cholqr_f64: n multiple of 32 (<= 256), ncols multiple of 64, ldy >= ncols even");
+  if (scratch_bytes < tadmm_cholqr_scratch_bytes(n, ncols)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "cholqr scratch too small");
+  hipStream_t s = (hipStream_t)stream_;
+  char* base = (char*)scratch;
+  size_t off = 0;
+  DgemmDesc* gd = (DgemmDesc*)(base + off); off += align_up(sizeof(DgemmDesc), 256);
+  CholDesc* cd = (CholDesc*)(base + off); off += align_up(sizeof(CholDesc), 256);
+  double* Cm = (double*)(base + off); off += align_up((size_t)n * n * 8, 256);
+  double* Rm = (double*)(base + off); off += align_up((size_t)n * n * 8, 256);
+  double* Wd = (double*)(base + off); off += align_up((size_t)n * 16 * 8, 256);
+  BlockRef* mg = (BlockRef*)(base + off); off += align_up((size_t)(n / 32) * (n / 32) * sizeof(BlockRef), 256);
+  BlockRef* ms = (BlockRef*)(base + off); off += align_up((size_t)(ncols / 64) * sizeof(BlockRef), 256);
+  int32_t* bad = (int32_t*)(base + off);
+  DgemmDesc g;
+  memset(&g, 0, sizeof g);
+  g.A = YT; g.B = YT; g.C = Cm; g.selA = g.selB = g.selC = g.selP = g.selQ = -1;
+  g.M = n; g.N = n; g.K = ncols; g.lda = ldy; g.ldb = ldy; g.ldc = n; g.tiles_m = n / 32; g.tiles_n = n / 32;
+  CholDesc c;
+  memset(&c, 0, sizeof c);
+  c.C = Cm; c.ldc = n; c.n = n; c.R = Rm; c.ldr = n; c.Wd = Wd;
+  c.ring[0] = YT; c.ring[1] = YT; c.ring[2] = YT; c.rot = nullptr; c.sel = 0; c.ldy = ldy; c.ncols = ncols; c.bad = bad;
+  std::vector<BlockRef> vg, vs;
+  for (int b = 0; b < g.tiles_m * g.tiles_n; ++b) vg.push_back(BlockRef{0, b});
+  for (int b = 0; b < ncols / 64; ++b) vs.push_back(BlockRef{0, b});
+  HIP_OK(h, hipMemsetAsync(bad, 0, 4, s));
+  HIP_OK(h, hipMemcpyAsync(gd, &g, sizeof g, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(cd, &c, sizeof c, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(mg, vg.data(), vg.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(ms, vs.data(), vs.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipStreamSynchronize(s));
+  launch_dgemm(gd, mg, (int)vg.size(), true, s);
+  launch_chol_factor(cd, 1, s);
+  launch_chol_solve(cd, ms, (int)vs.size(), s);
+  HIP_OK(h, hipMemcpyAsync(bad_out_host, bad, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(h, hipStreamSynchronize(s));
   HIP_OK(h, hipGetLastError());
   return TADMM_OK;
 }

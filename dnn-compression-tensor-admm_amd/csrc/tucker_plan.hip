@@ -25,7 +25,7 @@ using namespace tadmm;
 
 namespace {
 
-struct Arena {
+struct TkArena {
   size_t off = 0;
   size_t take(size_t bytes, size_t align = 256) {
     off = align_up(off, align);
@@ -151,7 +151,7 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
                          std::vector<char>* img, size_t desc_region, size_t* desc_bytes, size_t* total_bytes) {
   tadmm_handle h = P->h;
   const int n = P->n;
-  Arena da, ar;
+  TkArena da, ar;
   ar.off = desc_region;
   auto dev = [&](size_t off) -> char* { return base ? base + off : reinterpret_cast<char*>((uintptr_t)off); };
   auto put = [&](size_t off, const void* src, size_t bytes) {

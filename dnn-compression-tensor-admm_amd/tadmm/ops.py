@@ -111,6 +111,12 @@ class ProjectionPlan:
         keys = ["unfold_ms", "gram_ms", "eig_ms", "project_ms", "reconstruct_ms", "fold_update_ms", "jacobi_sweeps"]
         return {k: float(out[i]) for i, k in enumerate(keys)}
 
+    def filter_stats(self) -> dict:
+        """Filtered eigen-solver counters: eligible problems of the plan; of the last run: solves, fallbacks, stages."""
+        out = (C.c_int32 * 4)()
+        self.h.check(self.h.lib.tadmm_plan_filter_stats(self._plan, out))
+        return dict(eligible=int(out[0]), solves=int(out[1]), fallbacks=int(out[2]), stages=int(out[3]))
+
     def singular_values(self, layer: int, step: int) -> np.ndarray:
         r = self.ranks[layer][step + 1]
         out = (C.c_double * r)()
@@ -332,3 +338,33 @@ def eigh(G: torch.Tensor):
     h.check(lib.tadmm_eigh_f64(h.ptr, G.data_ptr(), N, ev.data_ptr(), vec.data_ptr(), scratch.data_ptr(), sb,
                                C.byref(sweeps), _stream(G.device)))
     return ev, vec, int(sweeps.value)
+
+
+# ------------------------------------------------------------------ filtered eigen-solver building blocks (tests)
+def dgemm(a: torch.Tensor, b: torch.Tensor, b_transposed: bool = True) -> torch.Tensor:
+    """fp64 matrix-core GEMM: a (M,K) @ b^T with b (N,K) (b_transposed) or a @ b with b (K,N); row-major float64."""
+    assert a.dtype == torch.float64 and b.dtype == torch.float64 and a.is_cuda and b.is_cuda
+    a, b = a.contiguous(), b.contiguous()
+    M, K = a.shape
+    N = b.shape[0] if b_transposed else b.shape[1]
+    out = torch.empty(M, N, dtype=torch.float64, device=a.device)
+    h = Handle.get(a.device.index)
+    sb = h.lib.tadmm_dgemm_scratch_bytes(M, N)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=a.device)
+    h.check(h.lib.tadmm_dgemm_f64(h.ptr, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
+                                  N, int(b_transposed), scratch.data_ptr(), sb, _stream(a.device)))
+    return out
+
+
+def cholqr_(yt: torch.Tensor) -> bool:
+    """In-place Cholesky QR of the block whose columns are the ROWS of yt (n, ncols) float64.  Returns False when a
+    pivot broke down (numerically rank-deficient block)."""
+    assert yt.dtype == torch.float64 and yt.is_cuda and yt.is_contiguous()
+    n, ncols = yt.shape
+    h = Handle.get(yt.device.index)
+    sb = h.lib.tadmm_cholqr_scratch_bytes(n, ncols)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=yt.device)
+    bad = C.c_int(0)
+    h.check(h.lib.tadmm_cholqr_f64(h.ptr, yt.data_ptr(), n, ncols, yt.stride(0), scratch.data_ptr(), sb, C.byref(bad),
+                                   _stream(yt.device)))
+    return bad.value == 0

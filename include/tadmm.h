@@ -116,6 +116,12 @@ int tadmm_plan_enable_timing(tadmm_plan p, int on);
  * sub-problems always get one cyclic sweep per visit), max_sweeps = cap before TADMM_ERR_NOCONVERGE.
  * <=0 keeps a value. */
 int tadmm_plan_set_jacobi(tadmm_plan p, double tol, int inner_sweeps, int max_sweeps);
+/* Filtered eigen-solver statistics (csrc/filter.hip): out[0] = eigen-problems of the plan served by the Chebyshev-
+ * filtered subspace path (those whose kept rank is a fraction of their size), and for the LAST run out[1] = filtered
+ * solves performed, out[2] = how many of them failed their a-posteriori check and were redone by the full Jacobi
+ * solve, out[3] = largest number of filter stages a level needed.  TADMM_FILTER=0 in the environment disables the
+ * path (every problem takes the full solve). */
+int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]);
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
 int tadmm_plan_destroy(tadmm_plan p);
@@ -194,6 +200,19 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
 size_t tadmm_eigh_scratch_bytes(int N);
 int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, double* evecs_out,
                    void* scratch_dev, size_t scratch_bytes, int* sweeps_out, void* stream);
+
+/* ---- building blocks of the filtered eigen-solver (csrc/dgemm.hip, csrc/chol.hip), exposed for tests ---- */
+/* C[M][N] = A[M][K] * B^T (b_transposed=1: B is [N][K]) or A * B (b_transposed=0: B is [K][N]); row-major fp64 on
+ * v_mfma_f64_16x16x4_f64.  M, N multiples of 32, K multiple of 16, even leading dimensions. */
+size_t tadmm_dgemm_scratch_bytes(int M, int N);
+int tadmm_dgemm_f64(tadmm_handle h, const double* A, const double* B, double* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, int b_transposed, void* scratch, size_t scratch_bytes, void* stream);
+/* Cholesky QR of a block stored as its transposed image YT[n][ldy] (row j = column j, `ncols` entries): on return the
+ * rows are orthonormal (one pass: to ~cond^2 * 1e-16).  *bad_out_host = 1 when a pivot broke down (numerically
+ * rank-deficient block; YT is then unspecified).  n multiple of 32, <= 256; ncols multiple of 64.  Synchronous. */
+size_t tadmm_cholqr_scratch_bytes(int n, int ncols);
+int tadmm_cholqr_f64(tadmm_handle h, double* YT, int n, int ncols, int ldy, void* scratch, size_t scratch_bytes,
+                     int* bad_out_host, void* stream);
 
 #ifdef __cplusplus
 }

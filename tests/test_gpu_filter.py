@@ -1,0 +1,141 @@
+"""GPU tests of the filtered eigen-solver (csrc/dgemm.hip, chol.hip, filter.hip): its building blocks against
+torch fp64, the filtered projection against the full Jacobi solve and the oracle, and the fall-back path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 16), (224, 512, 512), (96, 480, 224), (192, 192, 480)])
+def test_dgemm_nt_and_nn_match_torch_fp64(dev, shape):
+    from tadmm import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, dtype=torch.float64, generator=g).to(dev)
+    bt = torch.randn(N, K, dtype=torch.float64, generator=g).to(dev)
+    ref = a @ bt.t()
+    got = ops.dgemm(a, bt, True)
+    assert float((got - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) * np.sqrt(K)
+    b = bt.t().contiguous()
+    got2 = ops.dgemm(a, b, False)
+    assert float((got2 - ref).abs().max()) <= 1e-12 * float(ref.abs().max()) * np.sqrt(K)
+
+
+@pytest.mark.parametrize("n,ncols,cond", [(32, 64, 1e2), (128, 256, 1e4), (224, 512, 1e6), (192, 512, 1e3), (256, 512, 10.0)])
+def test_cholqr_orthonormalises_and_keeps_the_span(dev, n, ncols, cond):
+    from tadmm import ops
+    rng = np.random.default_rng(n + ncols)
+    q1, _ = np.linalg.qr(rng.standard_normal((ncols, n)))
+    q2, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.exp(np.linspace(0.0, -np.log(cond), n))
+    y = (q1 * s) @ q2.T                                   # ncols x n, condition number `cond`
+    yt = torch.from_numpy(np.ascontiguousarray(y.T)).to(dev)
+    assert ops.cholqr_(yt)
+    q = yt.cpu().numpy().T
+    err1 = np.abs(q.T @ q - np.eye(n)).max()
+    assert err1 <= 1e-13 * cond * cond + 1e-12, err1      # one pass: ~cond^2 * eps
+    assert ops.cholqr_(yt)
+    q = yt.cpu().numpy().T
+    assert np.abs(q.T @ q - np.eye(n)).max() <= 1e-13
+    # same column space: projecting the original block onto span(Q) reproduces it
+    assert np.linalg.norm(y - q @ (q.T @ y)) <= 1e-9 * np.linalg.norm(y)
+
+
+def test_cholqr_reports_rank_deficiency(dev):
+    from tadmm import ops
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((256, 40)) @ rng.standard_normal((40, 64))      # rank 40 < 64 columns
+    yt = torch.from_numpy(np.ascontiguousarray(y.T)).to(dev)
+    assert not ops.cholqr_(yt)
+
+
+def _layers(dev, rng, lowrank=None):
+    """a 3x3 conv (N = 240 / 256 Gram matrices, kept rank 82) and a 1x1 conv (N = 256, kept rank 75)"""
+    from tadmm._cabi import KIND_TT_CONV
+    specs = [((256, 256, 3, 3), [16, 16, 9, 16, 16], [1, 15, 82, 82, 15, 1]),
+             ((1024, 256, 1, 1), [1024, 1, 256], [1, 75, 75, 1])]
+    layers, ws = [], []
+    for shape, tts, ranks in specs:
+        fan_in = int(np.prod(shape[1:]))
+        w = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        if lowrank is not None:
+            m = w.reshape(shape[0], -1)
+            u, s, vt = np.linalg.svd(m, full_matrices=False)
+            w = ((u[:, :lowrank] * s[:lowrank]) @ vt[:lowrank]).reshape(shape).astype(np.float32)
+        ws.append(w)
+        t = torch.from_numpy(w).to(dev)
+        layers.append(dict(kind=KIND_TT_CONV, W=t, U=torch.zeros_like(t), Z=torch.empty_like(t), tt_shapes=tts,
+                           ranks=list(ranks)))
+    return specs, layers, ws
+
+
+def _run(layers, filt, monkeypatch, want_cores=False, sv_steps=(1, 2)):
+    from tadmm import ops
+    monkeypatch.setenv("TADMM_FILTER", "1" if filt else "0")
+    plan = ops.ProjectionPlan(layers, want_cores=want_cores)
+    plan.run(update_u=False, use_u=False)
+    z = [L["Z"].cpu().numpy().copy() for L in layers]
+    stats = plan.filter_stats()
+    sv = [plan.singular_values(0, k) for k in sv_steps]
+    plan.close()
+    return z, stats, sv
+
+
+def test_filtered_projection_matches_full_solve_and_oracle(dev, monkeypatch):
+    rng = np.random.default_rng(3)
+    specs, layers, ws = _layers(dev, rng)
+    zf, st_f, sv_f = _run(layers, True, monkeypatch)
+    zn, st_n, sv_n = _run(layers, False, monkeypatch)
+    assert st_n["eligible"] == 0 and st_f["eligible"] == 3 and st_f["solves"] == 3, (st_f, st_n)
+    assert st_f["fallbacks"] == 0, st_f
+    for a, b in zip(zf, zn):
+        assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
+    for a, b in zip(sv_f, sv_n):
+        np.testing.assert_allclose(a, b, rtol=1e-9)
+    for (shape, tts, ranks), w, z in zip(specs, ws, zf):
+        ref = O.prune_conv_rank_tt(w, tts, list(ranks))
+        assert np.linalg.norm(z - ref) <= 1e-5 * np.linalg.norm(ref)
+
+
+def test_filtered_projection_is_deterministic(dev, monkeypatch):
+    rng = np.random.default_rng(4)
+    _, layers, _ = _layers(dev, rng)
+    z1, _, _ = _run(layers, True, monkeypatch)
+    z2, _, _ = _run(layers, True, monkeypatch)
+    for a, b in zip(z1, z2):
+        assert np.array_equal(a, b)
+
+
+def test_low_rank_input_falls_back_to_the_full_solve(dev, monkeypatch):
+    """An exactly rank-40 weight: the filter's block is numerically rank deficient (Cholesky pivot breakdown), the
+    problem must be handed to the full Jacobi solve and the projection must return the input."""
+    rng = np.random.default_rng(5)
+    specs, layers, ws = _layers(dev, rng, lowrank=40)
+    zf, st, _ = _run(layers[1:], True, monkeypatch, sv_steps=())
+    assert st["eligible"] == 1 and st["fallbacks"] == 1, st
+    assert np.linalg.norm(zf[0] - ws[1]) <= 2e-6 * np.linalg.norm(ws[1])
+
+
+def test_filtered_cores_match_full_solve(dev, monkeypatch):
+    """want_cores (ten2tt / --decompose): individual Ritz vectors, not only their span, must agree with the full
+    solve; compared through the gauge-invariant reconstruction and the singular values."""
+    rng = np.random.default_rng(6)
+    _, layers, _ = _layers(dev, rng)
+    zf, st, sv_f = _run(layers, True, monkeypatch, want_cores=True)
+    zn, _, sv_n = _run(layers, False, monkeypatch, want_cores=True)
+    assert st["fallbacks"] == 0
+    for a, b in zip(zf, zn):
+        assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
+    for a, b in zip(sv_f, sv_n):
+        np.testing.assert_allclose(a, b, rtol=1e-9)
