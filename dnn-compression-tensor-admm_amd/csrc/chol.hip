@@ -22,7 +22,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kCT = 16;            // tile edge
 constexpr int kCLd = kCT + 1;      // padded leading dimension of the LDS tiles
 constexpr int kCMaxT = 16;         // n <= 256
-constexpr int kCSlots = (kCMaxT * (kCMaxT + 1) / 2 + 7) / 8;   // upper tiles per wave: 17
 
 __device__ __forceinline__ double rsqrt_f64(double x) {
   double y = __builtin_amdgcn_rsq(x);                    // ~2^-26 relative
@@ -102,11 +101,17 @@ __device__ __forceinline__ bool diag_inverse(const double (*Dg)[kCLd], double (*
   return ok;
 }
 
+// Wave 0 owns no tiles: it only inverts diagonal tiles, and does so for step k WHILE the other seven waves finish
+// the trailing update of step k-1 (look-ahead: the owner of tile (k,k) updates it first and hands it over).
+constexpr int kCTileWaves = 7;
+constexpr int kCSlots7 = (kCMaxT * (kCMaxT + 1) / 2 + kCTileWaves - 1) / kCTileWaves;   // 20
+
 __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __restrict__ descs) {
   __shared__ double Dg[kCT][kCLd];
   __shared__ double Wt[kCT][kCLd];
   __shared__ double Cb[kCT][5];        // current 16x4 block column of the diagonal tile's Schur complement
   __shared__ double Pn[kCMaxT][kCT][kCLd];
+  __shared__ double red[8];
   __shared__ unsigned char ti[kCMaxT * (kCMaxT + 1) / 2], tj[kCMaxT * (kCMaxT + 1) / 2];
   __shared__ int fail;
   const CholDesc d = descs[blockIdx.x];
@@ -123,12 +128,34 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
     ti[t] = (unsigned char)i; tj[t] = (unsigned char)(i + rem);
   }
   if (tid == 0) fail = 0;
-  __syncthreads();
-  double4_t acc[kCSlots];
   double scale = 0.0;                   // largest diagonal entry of C: pivots are judged relative to it
+  for (int i = tid; i < d.n; i += 512) scale = fmax(scale, d.C[(int64_t)i * d.ldc + i]);
 #pragma unroll
-  for (int s = 0; s < kCSlots; ++s) {
-    const int t = 8 * s + wave;
+  for (int o = 32; o > 0; o >>= 1) scale = fmax(scale, __shfl_xor(scale, o, 64));
+  if (lane == 0) red[wave] = scale;
+  __syncthreads();
+  scale = 0.0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) scale = fmax(scale, red[w]);
+  const double tiny = scale * 1e-15;    // a pivot this small relative to the largest norm: numerically rank deficient
+
+  if (wave == 0) {
+    // ---------------- diagonal wave ----------------
+    for (int k = 0; k < nbt; ++k) {
+      __syncthreads();                                             // A_k: tile (k,k) is in Dg
+      if (!diag_inverse(Dg, Cb, Wt, d.Wd + (int64_t)k * (kCT * kCT), lane, tiny) && lane == 0) fail = 1;
+      __syncthreads();                                             // B_k: W_k is in Wt (and trailing k-1 is complete)
+      if (fail) { if (tid == 0) *d.bad = 1; return; }
+      __syncthreads();                                             // C_k: panel k is in Pn
+    }
+    return;
+  }
+  // ---------------- tile waves ----------------
+  const int tw = wave - 1;
+  double4_t acc[kCSlots7];
+#pragma unroll
+  for (int s = 0; s < kCSlots7; ++s) {
+    const int t = kCTileWaves * s + tw;
     acc[s] = double4_t{0, 0, 0, 0};
     if (t < ntile) {
       const int i = __builtin_amdgcn_readfirstlane(ti[t]), j = __builtin_amdgcn_readfirstlane(tj[t]);
@@ -136,41 +163,46 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
       for (int e = 0; e < 4; ++e) acc[s][e] = d.C[(int64_t)(kCT * i + q + 4 * e) * d.ldc + kCT * j + r];
     }
   }
-  for (int i = tid; i < d.n; i += 512) scale = fmax(scale, d.C[(int64_t)i * d.ldc + i]);
+  // trailing update of ONE slot with the panel of step k (tile (i,j), i > k)
+  auto trail = [&](double4_t& a, int i, int j) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) scale = fmax(scale, __shfl_xor(scale, o, 64));
-  if (lane == 0) Pn[0][0][wave] = scale;
-  __syncthreads();
-  scale = 0.0;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) scale = fmax(scale, Pn[0][0][w]);
-  const double tiny = scale * 1e-15;    // a pivot this small relative to the largest norm: numerically rank deficient
-  __syncthreads();
-
-  for (int k = 0; k < nbt; ++k) {
+    for (int e = 0; e < 4; ++e)
+      a = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[i][q + 4 * e][r], Pn[j][q + 4 * e][r], a, 0, 0, 0);
+  };
+  // hand tile (k,k) to the diagonal wave
+  auto give_diag = [&](int k) {
     const int tkk = k * nbt - (k * (k - 1)) / 2;
-    // ---- 1. diagonal tile to LDS ----
 #pragma unroll
-    for (int s = 0; s < kCSlots; ++s)
-      if (8 * s + wave == tkk) {
+    for (int s = 0; s < kCSlots7; ++s)
+      if (kCTileWaves * s + tw == tkk) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) Dg[q + 4 * e][r] = acc[s][e];
       }
-    __syncthreads();
-    // ---- 2. W = L^-1 where Dg = L L^T, by wave 0 on the matrix cores in 4x4 blocks (see diag_inverse) ----
-    if (wave == 0) {
-      if (!diag_inverse(Dg, Cb, Wt, d.Wd + (int64_t)k * (kCT * kCT), lane, tiny) && lane == 0) fail = 1;
+  };
+  give_diag(0);
+  for (int k = 0; k < nbt; ++k) {
+    __syncthreads();                                               // A_k
+    // trailing update of step k-1 for everything but tile (k,k), which was updated before it was handed over
+    if (k > 0) {
+      const int tkk = k * nbt - (k * (k - 1)) / 2;
+#pragma unroll
+      for (int s = 0; s < kCSlots7; ++s) {
+        const int t = kCTileWaves * s + tw;
+        const int i = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
+        if (i > k - 1 && t != tkk) trail(acc[s], i, __builtin_amdgcn_readfirstlane(tj[t]));
+        __builtin_amdgcn_sched_barrier(0);     // keep the operand loads of one slot from being hoisted over the others
+      }
     }
-    __syncthreads();
-    if (fail) { if (tid == 0) *d.bad = 1; return; }
-    // ---- 3. panel R_kj = W C_kj (j > k) ----
+    __syncthreads();                                               // B_k
+    if (fail) return;
+    // ---- panel R_kj = W C_kj (j > k) ----
     {
       double wa[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) wa[e] = Wt[r][q + 4 * e];
 #pragma unroll
-      for (int s = 0; s < kCSlots; ++s) {
-        const int t = 8 * s + wave;
+      for (int s = 0; s < kCSlots7; ++s) {
+        const int t = kCTileWaves * s + tw;
         const int pi = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
         const int pj = t < ntile ? __builtin_amdgcn_readfirstlane(tj[t]) : -1;
         if (pi == k && pj > k) {
@@ -178,31 +210,24 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
 #pragma unroll
           for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[e], acc[s][e], o, 0, 0, 0);
           acc[s] = o;
-          const int j = pj;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            Pn[j][q + 4 * e][r] = o[e];
-            d.R[(int64_t)(kCT * k + q + 4 * e) * d.ldr + kCT * j + r] = o[e];
+            Pn[pj][q + 4 * e][r] = o[e];
+            d.R[(int64_t)(kCT * k + q + 4 * e) * d.ldr + kCT * pj + r] = o[e];
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();
-    // ---- 4. trailing update C_ij -= R_ki^T R_kj ----
+    __syncthreads();                                               // C_k
+    // ---- look-ahead: bring tile (k+1,k+1) up to date with panel k and hand it over ----
+    if (k + 1 < nbt) {
+      const int tnn = (k + 1) * nbt - ((k + 1) * k) / 2;
 #pragma unroll
-    for (int s = 0; s < kCSlots; ++s) {
-      const int t = 8 * s + wave;
-      const int i = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
-      if (i > k) {
-        const int j = __builtin_amdgcn_readfirstlane(tj[t]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pn[i][q + 4 * e][r], Pn[j][q + 4 * e][r], acc[s], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);     // keep the operand loads of one slot from being hoisted over the others
+      for (int s = 0; s < kCSlots7; ++s)
+        if (kCTileWaves * s + tw == tnn) trail(acc[s], k + 1, k + 1);
+      give_diag(k + 1);
     }
-    // (the next step's barriers order its LDS writes behind these reads)
   }
 }
 

@@ -168,6 +168,223 @@ void launch_dgemm(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nbloc
   else hipLaunchKernelGGL(dgemm_kernel<false>, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT product, 64x64 output tile per workgroup, operands staged through LDS (the workhorse of the filter: the
+// 32x32/K-split kernel above re-reads every operand row from L2 once per 32 output columns and is bound by the
+// CU's vector-memory path; here a row is fetched once per 64 and shared by two waves).
+//   4 waves in a 2x2 grid, each a 32x32 block = 2x2 MFMA tiles, full K per workgroup, K chunks of 32:
+//   global -> registers (next chunk, issued before the MFMAs of the current one) -> LDS -> MFMA operands.
+//   LDS rows hold 32 k-values + 2 doubles of padding: lane (r, q) reads row r at k = 4s + q, i.e. 8-byte word
+//   34 r + 4 s + q -- the 32 lanes of a ds_read_b64 group hit 32 distinct bank pairs.
+// M, N multiples of 32 (edge tiles are masked by 32-row halves), K multiple of 32.
+// Row partials of the epilogue modes 2/3 are per 64-column tile: rowpart[tn64][M].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDT = 64, kDK = 32, kDLd = kDK + 2;
+
+// TN = 64: 2x2 waves of 32x32;  TN = 32: 2x2 waves of 32x16 (half the work per workgroup: the grouped launches of the
+// filter have only a few hundred 64x64 tiles, and a chip of 256 CUs is filled evenly only by tasks well below
+// (total work / 256) in size).
+// KW = 2: eight waves, the second four take the upper half of every K chunk (partial sums folded through LDS at the
+// end).  A workgroup then keeps two waves on every SIMD of its CU and finishes in half the time: the grouped launches
+// of the filter put about one workgroup on a CU, whose duration IS the launch's.
+template <int TN, int KW>
+__global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc* __restrict__ descs,
+                                                               const BlockRef* __restrict__ map) {
+  constexpr int WN = TN / 2;            // columns per wave
+  constexpr int NB = WN / 16;           // B fragments per wave and k-step
+  constexpr int AP = 4 / KW;            // 16-byte pieces of A per thread and chunk (64 rows x 16 pieces / NT threads)
+  constexpr int BP = TN / 16 / KW;      // same for B (TN rows)
+  constexpr int RS = 16 * KW;           // row stride of a thread's pieces
+  constexpr int CPT = TN / 4;           // output columns per thread in the epilogue
+  constexpr int kBuf = (kDT + TN) * kDLd;          // doubles per LDS stage (A rows then B rows)
+  __shared__ __attribute__((aligned(16))) double smem[2 * kBuf > kDT * (TN + 1) ? 2 * kBuf : kDT * (TN + 1)];
+  __shared__ double rowred[kDT][4];
+  const BlockRef br = map[blockIdx.x];
+  const DgemmDesc d = descs[br.prob];
+  if (d.gate && *d.gate < d.gate_min) return;
+  const int base = d.rot ? *d.rot : 0;
+  const double* __restrict__ A = dg_sel(d, d.selA, d.A, base);
+  const double* __restrict__ B = dg_sel(d, d.selB, d.B, base);
+  double* __restrict__ C = const_cast<double*>(dg_sel(d, d.selC, d.C, base));
+  const int tiles_n = (d.N + TN - 1) / TN;
+  const int tm = br.local / tiles_n, tn = br.local - tm * tiles_n;
+  const int m0 = tm * kDT, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int K = d.K;
+  const int64_t lda = d.lda, ldb = d.ldb;
+  const bool live = (m0 + 32 * wm < d.M) && (n0 + WN * wn < d.N);      // this wave's block exists
+
+  // Pipeline: two LDS stages (one barrier per K chunk) and two register sets, so that a chunk's global loads are
+  // issued two chunks ahead of the LDS store that consumes them -- a workgroup's chunk (16-32 MFMAs per wave) is
+  // shorter than an L2 / Infinity-Cache round trip, and the grouped launches of the filter put only one or two
+  // workgroups on a CU.
+  struct Regs { double2_t a[AP], b[BP]; };
+  const int srow = tid >> 4, sc2 = tid & 15;                             // rows srow + RS i
+  // Rows beyond an edge are clamped, not predicated: a row of A (B) only feeds its own output row (column), which
+  // the epilogue never stores, and unconditional loads let the compiler count them (a branch per load makes it wait
+  // for vmcnt(0) at every LDS store, which serialises the whole prefetch).
+  const double* pa[AP]; const double* pb[BP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) pa[i] = A + (int64_t)min(m0 + srow + RS * i, d.M - 1) * lda + 2 * sc2;
+#pragma unroll
+  for (int i = 0; i < BP; ++i) pb[i] = B + (int64_t)min(n0 + srow + RS * i, d.N - 1) * ldb + 2 * sc2;
+  auto gload = [&](Regs& R, int k0) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) R.a[i] = *reinterpret_cast<const double2_t*>(pa[i] + k0);
+#pragma unroll
+    for (int i = 0; i < BP; ++i) R.b[i] = *reinterpret_cast<const double2_t*>(pb[i] + k0);
+  };
+  auto sstore = [&](const Regs& R, int stage) {
+    double (*As)[kDLd] = reinterpret_cast<double (*)[kDLd]>(smem + stage * kBuf);
+    double (*Bs)[kDLd] = As + kDT;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<double2_t*>(&As[srow + RS * i][2 * sc2]) = R.a[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<double2_t*>(&Bs[srow + RS * i][2 * sc2]) = R.b[i];
+  };
+  double4_t acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = double4_t{0, 0, 0, 0};
+  auto compute = [&](int stage) {
+    if (!live) return;
+    const double (*As)[kDLd] = reinterpret_cast<const double (*)[kDLd]>(smem + stage * kBuf);
+    const double (*Bs)[kDLd] = As + kDT;
+    const int kof = kh * (kDK / KW);                                      // this wave's part of the chunk
+    const double* a0p = &As[32 * wm + r][q + kof];
+    const double* a1p = &As[32 * wm + 16 + r][q + kof];
+    const double* b0p = &Bs[WN * wn + r][q + kof];
+    // all fragments of the chunk first (one burst of LDS reads, one wait), then the MFMAs back to back: left to
+    // itself the compiler waits for lgkmcnt(0) in front of every second k-step
+    constexpr int KS = kDK / KW / 4;
+    double fa0[KS], fa1[KS], fb[KS][NB];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      fa0[s] = a0p[4 * s]; fa1[s] = a1p[4 * s];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) fb[s][j] = b0p[16 * j * kDLd + 4 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s], fb[s][j], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s], fb[s][j], acc[1][j], 0, 0, 0);
+      }
+    }
+  };
+  const int nch = K / kDK;
+  constexpr int NPF = 2;                 // register sets: a chunk's loads are issued NPF chunks before its LDS store (deeper: no gain)
+  Regs R[NPF];
+#pragma unroll
+  for (int u = 0; u < NPF; ++u)
+    if (u < nch) gload(R[u], u * kDK);
+  sstore(R[0], 0);
+  if (NPF < nch) gload(R[0], NPF * kDK);
+  __syncthreads();
+  for (int c = 0; c < nch; c += NPF) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int i = c + u;               // chunk i sits in stage u & 1 (NPF is even)
+      if (i < nch) {
+        if (i + 1 < nch) {
+          sstore(R[(u + 1) % NPF], (u + 1) & 1);
+          if (i + 1 + NPF < nch) gload(R[(u + 1) % NPF], (i + 1 + NPF) * kDK);
+        }
+        compute(u & 1);
+        __syncthreads();
+      }
+    }
+  }
+  // accumulators -> LDS tile [64][TN+1] (aliases the staging buffers; the loop's last barrier has passed)
+  double (*Ct)[TN + 1] = reinterpret_cast<double (*)[TN + 1]>(smem);
+  if (KW == 2) {                        // upper k-half first, then the lower half adds its own sums
+    if (kh == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) Ct[32 * wm + 16 * i + q + 4 * e][WN * wn + 16 * j + r] = acc[i][j][e];
+    }
+    __syncthreads();
+  }
+  if (kh == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          double* c = &Ct[32 * wm + 16 * i + q + 4 * e][WN * wn + 16 * j + r];
+          *c = (KW == 2 ? *c : 0.0) + acc[i][j][e];
+        }
+  }
+  __syncthreads();
+  if (KW == 2 && tid >= 256) return;    // the epilogue is laid out for 256 threads
+  const int mode = d.mode;
+  double s0 = 1.0, s1 = 0.0, s2 = 0.0;
+  if (mode == 1) { s0 = d.coef[0]; s1 = d.coef[1]; s2 = d.coef[2]; }
+  const double* __restrict__ P = (mode >= 1) ? dg_sel(d, d.selP, d.P, base) : nullptr;
+  const double* __restrict__ Q = (mode == 1 && s2 != 0.0) ? dg_sel(d, d.selQ, d.Q, base) : nullptr;
+  const int64_t ldc = d.ldc;
+  const int row = tid >> 2, c0 = (tid & 3) * CPT;
+  const bool rok = m0 + row < d.M;
+  double part = 0.0;
+  if (rok && n0 + c0 < d.N) {                                            // N % 16 == 0: a thread's columns are in or out together
+    const double th = (mode == 3) ? d.theta[m0 + row] : 0.0;
+#pragma unroll
+    for (int u = 0; u < CPT; u += 2) {
+      const int col = c0 + u;
+      const int64_t gi = (int64_t)(m0 + row) * ldc + n0 + col;
+      const double v0 = Ct[row][col], v1 = Ct[row][col + 1];
+      if (mode == 0) {
+        *reinterpret_cast<double2_t*>(C + gi) = double2_t{v0, v1};
+      } else {
+        const double2_t p = *reinterpret_cast<const double2_t*>(P + gi);
+        if (mode == 1) {
+          double o0 = s0 * v0 + s1 * p.x, o1 = s0 * v1 + s1 * p.y;
+          if (Q) {
+            const double2_t qq = *reinterpret_cast<const double2_t*>(Q + gi);
+            o0 += s2 * qq.x; o1 += s2 * qq.y;
+          }
+          *reinterpret_cast<double2_t*>(C + gi) = double2_t{o0, o1};
+        } else if (mode == 2) {
+          *reinterpret_cast<double2_t*>(C + gi) = double2_t{v0, v1};
+          part += v0 * p.x + v1 * p.y;
+        } else {
+          const double e0 = v0 - th * p.x, e1 = v1 - th * p.y;
+          part += e0 * e0 + e1 * e1;
+        }
+      }
+    }
+  }
+  if (mode >= 2) {
+    rowred[row][tid & 3] = part;
+    __syncthreads();
+    if (tid < kDT && m0 + tid < d.M) {
+      const double* pr = rowred[tid];
+      d.rowpart[(int64_t)tn * d.M + m0 + tid] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+    }
+  }
+}
+
+void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n) {
+  if (nblocks <= 0) return;
+  static const int kw = getenv("TADMM_DGEMM_KW") ? atoi(getenv("TADMM_DGEMM_KW")) : 1;      // 2: eight-wave variant (A/B)
+  if (tile_n == 32) {
+    if (kw == 2) hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 2>), dim3(nblocks), dim3(512), 0, s, descs_dev, map_dev);
+    else hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 1>), dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  } else {
+    if (kw == 2) hipLaunchKernelGGL((dgemm_nt_tile_kernel<64, 2>), dim3(nblocks), dim3(512), 0, s, descs_dev, map_dev);
+    else hipLaunchKernelGGL((dgemm_nt_tile_kernel<64, 1>), dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
+  }
+}
+
 // Y <- s0*T + s1*Qb  (first Chebyshev step of a stage, in place of T); ring-addressed, gated like the products.
 __global__ __launch_bounds__(256) void daxpby_kernel(const DgemmDesc* __restrict__ descs, const BlockRef* __restrict__ map) {
   const BlockRef br = map[blockIdx.x];

@@ -10,10 +10,19 @@ namespace tadmm {
 static inline int filter_block_size(int N, int r) {
   const char* e = getenv("TADMM_FILTER");            // 0 disables the filtered path (A/B measurements, tests)
   if (e && !atoi(e)) return 0;
-  if (N < 192 || r < 16) return 0;
-  const int rp = (int)align_up((size_t)(1.55 * r + 0.999), 32);
+  int min_n = 192;
+  if (const char* m = getenv("TADMM_FILTER_MINN")) min_n = atoi(m);
+  if (N < min_n || r < 16) return 0;
+  double over = 1.55;
+  if (const char* o = getenv("TADMM_FILTER_OVERSAMPLE")) over = atof(o);
+  const int rp = (int)align_up((size_t)(over * r + 0.999), 32);
   if (rp > 256 || rp * 100 > 56 * N || rp <= r) return 0;
   return rp;
+}
+
+static inline int filter_tile_n() {
+  const char* e = getenv("TADMM_FILTER_TN");
+  return (e && atoi(e) == 64) ? 64 : 32;
 }
 
 struct FilterSpec {
@@ -71,7 +80,8 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
   for (int i = 0; i < nf; ++i) {
     const FilterSpec& sp = specs[i];
     const int rp = sp.rp, Npad = sp.Npad, r32 = (int)align_up(sp.r, 32), ldy = Npad, ldh = (int)align_up(rp, 128);
-    const int tn = Npad / 32, tr = rp / 32;
+    const int TNW = filter_tile_n();
+    const int tn = (Npad + TNW - 1) / TNW, tr = (rp + 63) / 64;      // 64 x TNW tiles of the NT products with G
     size_t ring_off[3];
     for (auto& o : ring_off) o = ar.take((size_t)rp * ldy * 8);
     const size_t st_off = ar.take(sizeof(FiltState));
@@ -205,11 +215,23 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     const int el_blocks = (int)(((size_t)rp * ldy + 1023) / 1024);
     for (int b = 0; b < el_blocks; ++b) { m_init.push_back(BlockRef{i, b}); m_axpby.push_back(BlockRef{i, b}); }
     for (int b = 0; b < tr * tn; ++b) m_stage0.push_back(BlockRef{i, b});
-    for (int b = 0; b < tr * tr; ++b) { m_gram.push_back(BlockRef{i, b}); m_hform.push_back(BlockRef{i, b}); }
-    for (int b = 0; b < (r32 / 32) * tn; ++b) { m_uform.push_back(BlockRef{i, b}); m_verify.push_back(BlockRef{i, b}); }
+    for (int b = 0; b < tr * ((rp + TNW - 1) / TNW); ++b) { m_gram.push_back(BlockRef{i, b}); m_hform.push_back(BlockRef{i, b}); }
+    for (int b = 0; b < (r32 / 32) * (Npad / 32); ++b) m_uform.push_back(BlockRef{i, b});     // NN kernel: 32x32 tiles
+    for (int b = 0; b < ((r32 + 63) / 64) * tn; ++b) m_verify.push_back(BlockRef{i, b});
     for (int b = 0; b < (sp.r + 3) / 4; ++b) m_emit.push_back(BlockRef{i, b});
     for (int b = 0; b < (int)align_up(Npad, 64) / 64; ++b) m_solve.push_back(BlockRef{i, b});
     (void)vh_off;
+  }
+  if (const char* e = getenv("TADMM_FILTER_XCD"); e && atoi(e)) {
+    std::vector<double> wk(nf);
+    for (int i = 0; i < nf; ++i) wk[i] = specs[i].Npad;          // cost of a block ~ its reduction length
+    xcd_by_problem(m_stage0, wk);
+    if (atoi(e) > 1) {
+      xcd_by_problem(m_gram, wk);
+      xcd_by_problem(m_hform, wk);
+      xcd_by_problem(m_verify, wk);
+      xcd_by_problem(m_solve, wk);
+    }
   }
   fg.prob_off = da.take(probs.size() * sizeof(FiltProb));
   if (img) img->put(fg.prob_off, probs.data(), probs.size() * sizeof(FiltProb));
@@ -253,6 +275,7 @@ static inline FiltParams filter_params(const FilterGroup& fg) {
   prm.cond_max = 1e6;
   prm.sin_tol = 5e-6;
   if (const char* e = getenv("TADMM_FILTER_EPS")) prm.log_target = log(2.0 / atof(e));
+  if (const char* e = getenv("TADMM_FILTER_COND")) prm.cond_max = atof(e);
   if (const char* e = getenv("TADMM_FILTER_SINTOL")) prm.sin_tol = atof(e);
   return prm;
 }
@@ -264,8 +287,8 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   auto D = [&](size_t off) { return ws + off; };
   const FiltProb* probs = (const FiltProb*)D(fg.prob_off);
   const FiltParams prm = filter_params(fg);
-  auto gemm = [&](const Phase& ph, bool bt = true) {
-    launch_dgemm((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, bt, s);
+  auto gemm = [&](const Phase& ph) {
+    launch_dgemm_nt64((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, s, filter_tile_n());
   };
   auto cholqr = [&](const Phase& gram, size_t chol_off) {
     gemm(gram);
@@ -278,15 +301,22 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   int smax = 12;
   if (const char* e = getenv("TADMM_FILTER_STAGES")) smax = std::max(1, atoi(e));
   int stages = 0;
+  // The stage logic runs on the device (gates); the host only has to stop launching.  It reads the verdict of stage
+  // st-1 ("did anyone filter?") after stage st's product + plan launches are queued, so it never waits for the GPU;
+  // the price is one stage of gated (empty) launches at the end.
   for (int st = 0; st < smax; ++st) {
     gemm(fg.p1);
-    launch_filt_plan(probs, fg.nf, prm, st == smax - 1, poll.host, s);
-    HIP_OK(h, hipEventRecord(poll.ev[0], s));
-    HIP_OK(h, hipEventSynchronize(poll.ev[0]));
-    bool any = false;
-    for (int q = 0; q < fg.nf; ++q) any = any || poll.host[1 + q] != 0;
-    if (!any) break;
-    ++stages;
+    int* slot = poll.host + (size_t)(st & 1) * poll.stride;
+    launch_filt_plan(probs, fg.nf, prm, st == smax - 1, slot, s);
+    HIP_OK(h, hipEventRecord(poll.ev[st & 1], s));
+    if (st > 0) {
+      HIP_OK(h, hipEventSynchronize(poll.ev[(st - 1) & 1]));
+      const int* prev = poll.host + (size_t)((st - 1) & 1) * poll.stride;
+      bool any = false;
+      for (int q = 0; q < fg.nf; ++q) any = any || prev[1 + q] != 0;
+      if (!any) break;
+      ++stages;
+    }
     launch_daxpby((const DgemmDesc*)D(fg.axpby.desc_off), (const BlockRef*)D(fg.axpby.map_off), fg.axpby.nblocks, s);
     for (const Phase& ph : fg.steps) gemm(ph);
     cholqr(fg.gramA, fg.cholA_off);
@@ -311,7 +341,7 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
   const FiltParams prm = filter_params(fg);
   launch_filt_theta(probs, fg.nf, s);
   launch_dgemm((const DgemmDesc*)D(fg.uform.desc_off), (const BlockRef*)D(fg.uform.map_off), fg.uform.nblocks, false, s);
-  launch_dgemm((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, true, s);
+  launch_dgemm_nt64((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, s, filter_tile_n());
   launch_filt_verdict(probs, fg.nf, prm, poll.host, s);
   launch_filt_emit(probs, (const BlockRef*)D(fg.emit.map_off), fg.emit.nblocks, s);
   HIP_OK(h, hipEventRecord(poll.ev[0], s));

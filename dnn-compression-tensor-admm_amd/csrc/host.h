@@ -88,6 +88,48 @@ static inline void xcd_group(std::vector<BlockRef>& m) {
   m.swap(out);
 }
 
+// Grouped launches whose problems are re-read many times by their own blocks (the block products of the filtered
+// eigen-solver: every 32x32 tile of a problem streams the problem's whole G and block image): give each PROBLEM to
+// one XCD, so that its operands stay in that XCD's 4 MiB L2 instead of being fetched by all eight.  Blocks i, i+8, ..
+// are observed to share an XCD; problems are dealt to the eight bins longest first, and a bin that runs dry steals
+// from the fullest one (balance over locality).  Placement is a speed matter only.
+static inline void xcd_by_problem(std::vector<BlockRef>& m, const std::vector<double>& weight) {
+  const char* e = getenv("TADMM_XCD_MAP");
+  if (e && !atoi(e)) return;
+  const int G = (int)m.size();
+  if (G < 64) return;
+  const int np = (int)weight.size();
+  std::vector<std::vector<BlockRef>> per(np);
+  for (const BlockRef& b : m) per[b.prob].push_back(b);
+  std::vector<int> order(np);
+  for (int i = 0; i < np; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return weight[a] * per[a].size() > weight[b] * per[b].size();
+  });
+  std::vector<std::vector<BlockRef>> bin(8);
+  double load[8] = {0};
+  for (int p : order) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+    load[best] += weight[p] * per[p].size();
+    bin[best].insert(bin[best].end(), per[p].begin(), per[p].end());
+  }
+  size_t head[8] = {0};
+  std::vector<BlockRef> out;
+  out.reserve(G);
+  for (int i = 0; (int)out.size() < G; ++i) {
+    int x = i & 7;
+    if (head[x] >= bin[x].size()) {         // dry: steal from the bin with the most blocks left
+      int full = -1; size_t left = 0;
+      for (int y = 0; y < 8; ++y) if (bin[y].size() - head[y] > left) { left = bin[y].size() - head[y]; full = y; }
+      if (full < 0) break;
+      x = full;
+    }
+    out.push_back(bin[x][head[x]++]);
+  }
+  m.swap(out);
+}
+
 // Which Jacobi kernel a group of problems whose longest row is ld_max uses:
 // 3 = tick3 (carried self-Grams) + self pass, 1 = LDS super-pair, 0 = plain pair kernel.
 // TADMM_JACOBI_MODE (0 | 1 | 3) overrides the preference, never the capacity checks.

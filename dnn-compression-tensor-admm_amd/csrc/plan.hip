@@ -1144,7 +1144,15 @@ int tadmm_dgemm_f64(tadmm_handle h, const double* A, const double* B, double* C,
   HIP_OK(h, hipMemcpyAsync(gd, &g, sizeof g, hipMemcpyHostToDevice, s));
   HIP_OK(h, hipMemcpyAsync(md, map.data(), map.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipStreamSynchronize(s));
-  launch_dgemm(gd, md, (int)map.size(), b_transposed != 0, s);
+  if (b_transposed && K % 32 == 0 && !getenv("TADMM_DGEMM_OLD")) {        // the 64x64 LDS-staged kernel (what the filter uses)
+    std::vector<BlockRef> m64;
+    for (int b = 0; b < ((M + 63) / 64) * ((N + 63) / 64); ++b) m64.push_back(BlockRef{0, b});
+    HIP_OK(h, hipMemcpyAsync(md, m64.data(), m64.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+    HIP_OK(h, hipStreamSynchronize(s));
+    launch_dgemm_nt64(gd, md, (int)m64.size(), s);
+  } else {
+    launch_dgemm(gd, md, (int)map.size(), b_transposed != 0, s);
+  }
   HIP_OK(h, hipGetLastError());
   return TADMM_OK;
 }
@@ -1190,7 +1198,7 @@ int tadmm_cholqr_f64(tadmm_handle h, double* YT, int n, int ncols, int ldy, void
   HIP_OK(h, hipMemcpyAsync(mg, vg.data(), vg.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipMemcpyAsync(ms, vs.data(), vs.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipStreamSynchronize(s));
-  launch_dgemm(gd, mg, (int)vg.size(), true, s);
+  launch_dgemm(gd, mg, (int)vg.size(), true, s);     // (32x32 kernel: ncols is only required to be a multiple of 16)
   launch_chol_factor(cd, 1, s);
   launch_chol_solve(cd, ms, (int)vs.size(), s);
   HIP_OK(h, hipMemcpyAsync(bad_out_host, bad, 4, hipMemcpyDeviceToHost, s));
