@@ -5,15 +5,21 @@
 
 One *step* = one ADMM projection iteration over every compressed layer of the rank table
 (ADMM.update(update_u=True) semantics: Z <- proj(W+U), U += W-Z, ||W-Z||^2).  Inputs are synthetic
-(N(0, 2/fan_in), seed 0) and resident in HBM before the timed region.  With N > 1 (launched by
-torch.distributed.run) the layers are sharded over the ranks by LPT and the only collective is one
-RCCL all-reduce of the scalar residual per step; total work is fixed => "scaling": "strong".
+(N(0, 2/fan_in), seed 0) and resident in HBM before the timed region.
+
+`--gpus N` with N > 1 and no torch.distributed environment starts the N ranks itself (a child
+`python -m torch.distributed.run ... bench.py`, before this process touches the GPU).  At N > 1 `value` is ONE
+table's iterations/s with its layers sharded over the ranks (strong scaling, BASELINE.json north_star; the only
+collective is one RCCL all-reduce of the scalar residual per step); the throughput of N tables, one per rank, is
+reported beside it under `weak_scaling`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,12 +27,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "dnn-compression-tensor-admm_amd"))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 PEAK_F64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (vendor figure; = fp64 vector peak on CDNA4)
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="resnet50_tt")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-per-layer", action="store_true")
+    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the one-table-per-rank (weak scaling) pass")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: time every part of an N-way layer shard one after the other on this GPU")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`--gpus N` without a rendezvous environment: start the N ranks as a child launcher.  Nothing in this process
+    has touched the GPU yet (torch is not even imported), so no process that initialised HIP is ever replaced."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def layer_entries(model, hp, fmt, dev):
@@ -48,7 +80,10 @@ def layer_entries(model, hp, fmt, dev):
 
 
 def cpu_baseline(config, max_seconds=30.0):
-    """The oracle (numpy -> LAPACK sgesdd, same call sequence as ttd.py/admm.py) timed on the host cores."""
+    """The oracle (numpy -> LAPACK sgesdd, same call sequence as ttd.py/admm.py) timed on the host cores: one sweep at
+    each of a few BLAS thread counts (the box's full core count oversubscribes these small SVDs), the fastest one is
+    reported with the thread count it used."""
+    import numpy as np
     from oracle import tt_oracle as O
     from tadmm import workloads
     model, hp, fmt = workloads.build(config, seed=0)
@@ -56,72 +91,75 @@ def cpu_baseline(config, max_seconds=30.0):
     u = {k: np.zeros_like(v) for k, v in w.items()}
     ranks = {k: (list(v) if not isinstance(v, int) else v) for k, v in hp.ranks.items()}
     tts = getattr(hp, "tt_shapes", None)
-    t0 = time.perf_counter()
-    O.admm_update(w, u, fmt, ranks, tts)         # warm-up sweep (BLAS thread pool, page faults)
-    warm = time.perf_counter() - t0
-    times = []
-    while sum(times) + warm < max_seconds and len(times) < 3:
-        t0 = time.perf_counter()
-        O.admm_update(w, u, fmt, ranks, tts)
-        times.append(time.perf_counter() - t0)
-        if times[-1] > max_seconds / 2:
-            break
-    if not times:
-        times = [warm]
-    best = float(np.median(times))
-    threads = os.cpu_count()
+    ncpu = os.cpu_count() or 1
+    tried = {}
+    t_start = time.perf_counter()
     try:
-        from threadpoolctl import threadpool_info
-        th = [i.get("num_threads") for i in threadpool_info() if i.get("user_api") == "blas"]
-        if th:
-            threads = int(max(th))
+        from threadpoolctl import threadpool_limits
     except Exception:
-        pass
-    return dict(value=1.0 / best, unit="iters/s", cores=threads, kind="port",
-                sample=f"{len(times)} full {config} sweep(s) after 1 warm-up sweep, median, numpy {np.__version__} LAPACK sgesdd",
-                seconds_per_sweep=best)
+        threadpool_limits = None
+    candidates = [c for c in (16, 8, 32, ncpu) if c <= ncpu] or [ncpu]
+    seen = set()
+    for th in candidates:
+        if th in seen or (time.perf_counter() - t_start) > max_seconds:
+            continue
+        seen.add(th)
+        def sweep():
+            t0 = time.perf_counter()
+            O.admm_update(w, u, fmt, ranks, tts)
+            return time.perf_counter() - t0
+        if threadpool_limits is not None:
+            with threadpool_limits(limits=th, user_api="blas"):
+                if not tried:
+                    sweep()                      # warm-up (thread pool, page faults), not counted
+                tried[th] = sweep()
+        else:
+            tried[ncpu] = sweep()
+            break
+    best_th = min(tried, key=tried.get)
+    best = tried[best_th]
+    return dict(value=1.0 / best, unit="iters/s", cores=int(best_th), kind="port",
+                sample=f"one full {config} sweep per BLAS thread count {sorted(tried)} after a warm-up sweep; fastest "
+                       f"reported; numpy {np.__version__} LAPACK sgesdd; host has {ncpu} cores",
+                seconds_per_sweep=best, seconds_by_threads={str(k): v for k, v in tried.items()})
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="resnet50_tt")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N>1: weak = one table per rank (headline, value = tables x it/s), with the strong variant "
-                         "timed beside it; strong = only ONE table LPT-sharded over the ranks")
-    ap.add_argument("--emulate-world", type=int, default=0,
-                    help="diagnostic: time every part of an N-way layer shard one after the other on this GPU")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per requested GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
-    dev = torch.device("cuda", local % ndev)          # one rank per GPU (rehearsals may fold ranks onto one card)
+    dev = torch.device("cuda", local % ndev)          # one rank per GPU; a rehearsal on fewer cards folds ranks
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("TADMM_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for rehearsals
-        if backend == "nccl":
+        if backend == "nccl" and ndev >= world:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group("gloo" if ndev < world else backend, rank=rank, world_size=world)
 
     from tadmm import ops, sched, workloads
     model, hp, fmt = workloads.build(args.config, seed=0)
     entries, names = layer_entries(model, hp, fmt, dev)
     flops = [sched.layer_flops(e["kind"], list(e["W"].shape), e.get("tt_shapes"), e["ranks"]) for e in entries]
     costs = [f["svd"] + f["rec"] for f in flops]
+    profiles = [sched.layer_latency_profile(e["kind"], list(e["W"].shape), e.get("tt_shapes"), e["ranks"]) for e in entries]
     if args.emulate_world > 1:
-        emu = sched.lpt_partition(costs, args.emulate_world)
+        emu = sched.latency_partition(profiles, args.emulate_world)
         res = []
         for part in emu:
             for i in part:
@@ -136,6 +174,7 @@ def main():
                 pl.run(update_u=True)
             torch.cuda.synchronize()
             res.append(dict(layers=len(part), ms=1e3 * (time.perf_counter() - t0) / args.steps,
+                            model_ms=sched.rank_time_us([profiles[i] for i in part]) / 1e3,
                             gflop=sum(costs[i] for i in part) / 1e9, names=[names[i] for i in part][:4]))
             pl.close()
         print(json.dumps({"emulate_world": args.emulate_world, "max_ms": max(r["ms"] for r in res), "parts": res}))
@@ -177,100 +216,150 @@ def main():
             ents[i]["Z"] = torch.empty_like(ents[i]["W"])
         return ops.ProjectionPlan([ents[i] for i in idx]) if idx else None
 
-    # Layers are independent units (admm.py:43), so the N-GPU job shards them with no data-path collective.
-    # Headline (weak scaling, per-GPU work fixed): N tables of the configuration (table r seeded r, e.g. N models
-    # or N rho/rank settings being compressed at once), rank r projecting table r; value = tables x iterations/s.
-    # The strong-scaling variant north_star also asks for (ONE table LPT-sharded over the ranks) is timed right
-    # after and reported beside it under "strong_scaling" -- it is bounded by the latency of one layer's chain of
-    # eigen-solves.
-    strong = None
-    if world > 1 and args.scaling == "weak":
-        parts = sched.lpt_partition(costs, world)
-        splan = make_plan(entries, parts[rank])
-        sel = timed(splan)
-        strong = {"value": args.steps / sel, "unit": "iters/s", "ms_per_step": 1e3 * sel / args.steps,
-                  "layers_per_rank": [len(p_) for p_ in parts], "residual_sq": float(total_resid[0]),
-                  "note": "ONE table, layers LPT-sharded over the ranks, same K/W"}
-        if splan is not None:
-            splan.close()
-        del splan
-        model, hp, fmt = workloads.build(args.config, seed=rank)
-        entries, names = layer_entries(model, hp, fmt, dev)
-        mine = list(range(len(entries)))
-        parts = [mine] * world
-        tables = world
-    else:
-        parts = sched.lpt_partition(costs, world)
-        mine = parts[rank]
-        tables = 1
+    # ---- headline: ONE table; its layers are independent units (admm.py:43) sharded over the ranks by the latency
+    #      model of sched.py; no data-path collective ----
+    parts = sched.latency_partition(profiles, world)
+    mine = parts[rank]
     plan = make_plan(entries, mine)
     elapsed = timed(plan)
-
+    resid_headline = float(total_resid[0])
     ms_per_step = 1e3 * elapsed / args.steps
-    iters_per_s = tables * args.steps / elapsed
+    iters_per_s = args.steps / elapsed
     tot = {k: sum(f[k] for f in flops) for k in ("svd", "rec", "gram", "proj", "eig", "numel")}
+    mfma_able = tot["gram"] + tot["proj"] + tot["rec"]
     out = {
         "metric": "ADMM projection iters/sec (all layers) + per-layer SVD GFLOP/s, ResNet-50 TT ranks",
         "value": iters_per_s, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if tables > 1 or world == 1 else "strong",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
-        "dtype": "f32 (Gram + eigen-solve accumulate in f64)", "data": "synthetic",
+        "dtype": "f32 (Gram, eigen-solve and its filter products accumulate in f64)", "data": "synthetic",
         "config": {"workload": f"{args.config}: {len(entries)} layers, {int(tot['numel'])} weights, "
                                f"hp table {workloads.CONFIGS[args.config][0]}",
-                   "tables": tables, "layers_per_rank": [len(p) for p in parts],
-                   "parallelism": f"layer-shard x{world}" + (f" ({tables} tables, one per rank)" if tables > 1 else "")},
+                   "tables": 1, "layers_per_rank": [len(p) for p in parts],
+                   "parallelism": f"layer-shard x{world} (latency-model partition, one scalar all-reduce per step)"},
         "svd_gflops_per_s": (tot["svd"] + tot["rec"]) * iters_per_s / 1e9,
+        "svd_gflops_note": "thin-SVD model 4MN^2 + 8N^3 per unfolding + tt2ten chain, over ALL TT steps of the table -- "
+                           "including the identity steps the Z-only projection skips (kept rank = row count; "
+                           "TADMM_FLAG_SKIP_ROTATIONS) and the eigen-problems solved for their leading r vectors only",
         "algorithmic_gflop_per_iter": {k: v / 1e9 for k, v in tot.items() if k != "numel"},
-        "residual_sq": float(total_resid[0]),
+        "residual_sq": resid_headline,
     }
-    if strong is not None:
-        out["strong_scaling"] = strong
+    if ndev < world:
+        out["folded_on"] = ndev      # rehearsal: several ranks share a card, the figure is not a scaling point
+    if world > 1:
+        out["strong_scaling_model_ms"] = {"per_rank": [sched.rank_time_us([profiles[i] for i in p]) / 1e3 for p in parts],
+                                          "note": "sched.rank_time_us: one layer's chain of eigen-solves is latency-bound, "
+                                                  "so sharding layers cannot shorten the longest chain (DESIGN.md)"}
+
+    # north_star's yardstick: MFMA-able FLOPs of the whole sweep against the fp32 matrix peak
+    out["roofline_sweep"] = {"bound": "mfma", "achieved": mfma_able / (ms_per_step * 1e-3) / 1e12,
+                             "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                             "frac": mfma_able / (ms_per_step * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                             "note": "Gram + projection + chain GEMM FLOPs of one iteration (SURVEY 8d) / ms_per_step / "
+                                     "fp32 MFMA peak: the whole-sweep figure north_star's 40 % target refers to"}
 
     if rank == 0 and plan is not None and not args.no_roofline:
-        # instrumented pass: HIP events around each phase on the launch stream (adds syncs, so it is
-        # separate from the timed region above)
+        # instrumented pass: HIP events around each phase on the launch stream, and around every launch of the
+        # dominant kernel (adds syncs, so it is separate from the timed region above)
         plan.enable_timing(True)
-        acc = None
+        acc, ft = None, dict(gemm_ms=0.0, gemm_launches=0, gemm_flops=0.0)
         reps = max(3, min(args.steps, 10))
         for _ in range(reps):
             plan.run(update_u=True)
             t = plan.last_timing()
+            f = plan.filter_timing()
             acc = t if acc is None else {k: acc[k] + t[k] for k in t}
+            ft = {k: ft[k] + f[k] for k in ft}
         ph = {k: v / reps for k, v in acc.items()}
         plan.enable_timing(False)
+        fstats = plan.filter_stats()
         my_gram = sum(flops[i]["gram"] for i in mine)
         my_mfma32 = sum(flops[i]["proj"] + flops[i]["rec"] for i in mine)
         my_bytes = 16.0 * sum(flops[i]["numel"] for i in mine)
-        gram_tf = my_gram / (ph["gram_ms"] * 1e-3) / 1e12 if ph["gram_ms"] > 0 else 0.0
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-               # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); bench.py cannot run rocprofv3 itself
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if args.config == "resnet50_tt" and world == 1:
-                traffic = pm["kernels"]["gram_partial_kernel"]["hbm_bytes_per_launch_corrected"]
-                traffic_src = "profiles/r01_pmc_traffic.json (per launch of gram_partial_kernel)"
+        pm = {}
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE
+               # doubled as MI355X_MICROARCH.md prescribes); bench.py cannot run rocprofv3 itself
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
         except Exception:
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": "gram_partial_kernel+gram_reduce_kernel (fp64 MFMA 16x16x4)",
-                           "achieved": gram_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": gram_tf / PEAK_F64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                           "launches_per_step": 4,
-                           "note": "dominant MATRIX-CORE kernel; algorithmic 2*M*N^2 per unfolding (18.63 GFLOP/step) / "
-                                   "HIP-event time of the Gram launches on rank 0.  The dominant kernel by TIME is the "
-                                   "latency-bound Jacobi tick (see phases_ms / roofline_other.eig_time_share)."}
+        total_ms = sum(v for k, v in ph.items() if k.endswith("_ms"))
+        if ft["gemm_launches"] > 0 and ft["gemm_ms"] > 0:
+            gemm_tf = ft["gemm_flops"] / (ft["gemm_ms"] * 1e-3) / 1e12
+            traffic = pm.get("dgemm_nt_tile_kernel", {}).get("hbm_bytes_per_launch_corrected") \
+                if args.config == "resnet50_tt" and world == 1 else None
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "dgemm_nt_tile_kernel<32,1> (fp64 MFMA 16x16x4: block products of the "
+                                           "filtered eigen-solver)",
+                "achieved": gemm_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F64_MFMA_TFLOPS,
+                "traffic": traffic,
+                "traffic_source": "profiles/r02_pmc_traffic.json (per launch)" if traffic else None,
+                "launches_per_step": ft["gemm_launches"] / reps,
+                "avg_launch_us": 1e3 * ft["gemm_ms"] / ft["gemm_launches"],
+                "time_share": (ft["gemm_ms"] / reps) / max(1e-9, total_ms),
+                "flops_per_step": ft["gemm_flops"] / reps,
+                "note": "dominant kernel by time.  achieved = 2*M*N*K of every product the launches executed "
+                        "(gated-off problems excluded; read back from the device) / their HIP-event time, each launch "
+                        "timed on the launch stream.  These FLOPs are the work of the filter, not part of the "
+                        "thin-SVD model"}
         gemm_ms = ph["project_ms"] + ph["reconstruct_ms"]
         sweep_ms = ph["unfold_ms"] + ph["fold_update_ms"]
         out["phases_ms"] = ph
+        out["filter"] = fstats
         out["roofline_other"] = {
+            "gram_f64_mfma": {"achieved_tflops": my_gram / (ph["gram_ms"] * 1e-3) / 1e12 if ph["gram_ms"] > 0 else 0.0,
+                              "peak_tflops": PEAK_F64_MFMA_TFLOPS, "algorithmic_gflop": my_gram / 1e9},
             "gemm_f32_mfma": {"achieved_tflops": my_mfma32 / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                               "peak_tflops": PEAK_F32_MFMA_TFLOPS},
             "hbm_sweeps": {"achieved_gbs": my_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0,
                            "peak_gbs": PEAK_HBM_GBS, "algorithmic_bytes": my_bytes},
-            "eig_time_share": ph["eig_ms"] / max(1e-9, sum(v for k, v in ph.items() if k.endswith("_ms"))),
-            # the eigen-solve against the fp64 matrix peak, with the implementation-independent 8*N^3 model
+            "eig_time_share": ph["eig_ms"] / max(1e-9, total_ms),
+            # the whole eigen phase (filter + Rayleigh-Ritz Jacobi + fallbacks) against the fp64 matrix peak, with the
+            # implementation-independent 8*N^3 model of a full symmetric eigen-decomposition
             "eig_f64": {"algorithmic_tflops": sum(flops[i]["eig"] for i in mine) / (ph["eig_ms"] * 1e-3) / 1e12
-                        if ph["eig_ms"] > 0 else 0.0, "peak_tflops": PEAK_F64_MFMA_TFLOPS},
+                        if ph["eig_ms"] > 0 else 0.0, "peak_tflops": PEAK_F64_MFMA_TFLOPS,
+                        "jacobi_tick3": pm.get("jacobi_tick3_kernel")},
         }
+
+    # ---- per-layer SVD GFLOP/s: every distinct layer shape projected ALONE (own single-layer plan) ----
+    if rank == 0 and world == 1 and not args.no_per_layer:
+        seen, per_layer = {}, []
+        for i, e in enumerate(entries):
+            sig = (tuple(e["W"].shape), tuple(e.get("tt_shapes") or ()), str(e["ranks"]))
+            if sig in seen:
+                seen[sig]["count"] += 1
+                continue
+            one = dict(e)
+            one["U"] = torch.zeros_like(e["W"])
+            one["Z"] = torch.empty_like(e["W"])
+            pl = ops.ProjectionPlan([one])
+            for _ in range(2):
+                pl.run(update_u=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 5
+            for _ in range(n):
+                pl.run(update_u=True)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / n
+            pl.close()
+            rec = {"layer": names[i], "shape": list(e["W"].shape), "count": 1, "svd_gflop": costs[i] / 1e9, "ms_alone": ms,
+                   "svd_gflops_per_s": costs[i] / (ms * 1e-3) / 1e9}
+            seen[sig] = rec
+            per_layer.append(rec)
+        out["per_layer_svd_gflops"] = per_layer
+
+    # ---- weak scaling beside the headline: N tables of the configuration, table r seeded r on rank r ----
+    if world > 1 and not args.no_weak:
+        if plan is not None:
+            plan.close()
+        del plan
+        model, hp, fmt = workloads.build(args.config, seed=rank)
+        wentries, _ = layer_entries(model, hp, fmt, dev)
+        wplan = make_plan(wentries, list(range(len(wentries))))
+        wel = timed(wplan)
+        out["weak_scaling"] = {"value": world * args.steps / wel, "unit": "tables x iters/s", "tables": world,
+                               "ms_per_step": 1e3 * wel / args.steps,
+                               "note": "one table per rank (table r seeded r), no data-path collective, same K/W"}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.config)
     if rank == 0:

@@ -178,7 +178,8 @@ struct FiltState {
   int32_t active;             // 1 while another stage is wanted
   int32_t alive;              // 0 once the problem has been handed to the fallback solver
   int32_t bad;                // sticky failure word (pivot breakdown, degenerate bounds, failed verification)
-  int32_t stage, pad;
+  int32_t stage;
+  int32_t products;           // block products with G this run (stage-0 product, recurrence steps, final T)
   double logamp;              // accumulated log-amplification of the boundary Ritz vector relative to the damped part
   double coef1[2];            // first step of a stage:  Y1 = coef1[0]*T + coef1[1]*Q           (T = G Q)
   double coefk[3];            // later steps: Y_{k+1} = coefk[0]*G*Y_k + coefk[1]*Y_k + coefk[2]*Y_{k-1}

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void filt_init_kernel(const FiltProb* __restri
   if (br.local == 0 && threadIdx.x == 0) {
     FiltState* st = p.st;
     st->base = 0; st->res = 1; st->nsteps = 0; st->active = 1; st->alive = 1; st->bad = 0; st->stage = 0;
+    st->products = 2;       // stage-0 product + the product in front of the Rayleigh-Ritz projection
     st->logamp = 0.0; st->crit = 0.0; st->b = st->lr = st->l1 = 0.0;
     *p.skip_slot = 0;
     *p.fb_skip = 0;
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void filt_plan_kernel(const FiltProb* __restri
       st->bad = 1; st->alive = 0; *p.skip_slot = 1;
     }
     st->nsteps = m;
+    st->products += (m > 0) ? m : 1;     // the stage's first product was launched before its degree was known
     int res = st->base + m;
     res -= (res >= 3) ? 3 : 0; res -= (res >= 3) ? 3 : 0; res -= (res >= 3) ? 3 : 0;
     st->res = res % 3;

@@ -35,6 +35,13 @@ struct FilterSpec {
   int32_t* fb_skip = nullptr;       // device word in the skip array of the fallback group
 };
 
+// instrumented runs only (tadmm_plan_enable_timing): the fp64 GEMM launches of the filter are timed one by one
+struct FilterTiming {
+  bool on = false;
+  hipEvent_t a{}, b{};
+  double gemm_ms = 0.0; int gemm_launches = 0; double gemm_flops = 0.0;
+};
+
 struct FilterGroup {
   int nf = 0;
   int max_degree = 8;
@@ -282,13 +289,23 @@ static inline FiltParams filter_params(const FilterGroup& fg) {
 
 // Part 1: filter + orthonormalise + form the Rayleigh-Ritz images.  One host wait per stage ("anyone still
 // filtering?", a word per problem in pinned memory).
-static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, PollCtx& poll, hipStream_t s, bool debug) {
+static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, PollCtx& poll, hipStream_t s, bool debug,
+                                 FilterTiming* tm = nullptr) {
   if (fg.nf == 0) return TADMM_OK;
   auto D = [&](size_t off) { return ws + off; };
   const FiltProb* probs = (const FiltProb*)D(fg.prob_off);
   const FiltParams prm = filter_params(fg);
   auto gemm = [&](const Phase& ph) {
+    const bool t = tm && tm->on;
+    if (t) (void)hipEventRecord(tm->a, s);
     launch_dgemm_nt64((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, s, filter_tile_n());
+    if (t) {
+      float ms = 0.f;
+      (void)hipEventRecord(tm->b, s);
+      (void)hipEventSynchronize(tm->b);
+      (void)hipEventElapsedTime(&ms, tm->a, tm->b);
+      tm->gemm_ms += ms; tm->gemm_launches += 1;
+    }
   };
   auto cholqr = [&](const Phase& gram, size_t chol_off) {
     gemm(gram);
@@ -333,7 +350,7 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
 // Part 2 (after the Rayleigh-Ritz solve + eig_norms/sort/extract of the group): Ritz vectors, verification, outputs.
 // Returns the number of problems that must take the fallback solve in *nbad.
 static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, PollCtx& poll, hipStream_t s, bool debug,
-                                  int* nbad) {
+                                  int* nbad, FilterTiming* tm = nullptr) {
   *nbad = 0;
   if (fg.nf == 0) return TADMM_OK;
   auto D = [&](size_t off) { return ws + off; };
@@ -341,7 +358,18 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
   const FiltParams prm = filter_params(fg);
   launch_filt_theta(probs, fg.nf, s);
   launch_dgemm((const DgemmDesc*)D(fg.uform.desc_off), (const BlockRef*)D(fg.uform.map_off), fg.uform.nblocks, false, s);
-  launch_dgemm_nt64((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, s, filter_tile_n());
+  {
+    const bool t = tm && tm->on;
+    if (t) (void)hipEventRecord(tm->a, s);
+    launch_dgemm_nt64((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, s, filter_tile_n());
+    if (t) {
+      float ms = 0.f;
+      (void)hipEventRecord(tm->b, s);
+      (void)hipEventSynchronize(tm->b);
+      (void)hipEventElapsedTime(&ms, tm->a, tm->b);
+      tm->gemm_ms += ms; tm->gemm_launches += 1;
+    }
+  }
   launch_filt_verdict(probs, fg.nf, prm, poll.host, s);
   launch_filt_emit(probs, (const BlockRef*)D(fg.emit.map_off), fg.emit.nblocks, s);
   HIP_OK(h, hipEventRecord(poll.ev[0], s));
@@ -350,6 +378,20 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
   for (int q = 0; q < fg.nf; ++q) bad += poll.host[1 + q] ? 0 : 1;
   *nbad = bad;
   fg.last_bad = bad;
+  if (tm && tm->on) {     // executed FLOPs of the timed GEMM launches: products + Grams + projection + residuals
+    std::vector<FiltProb> hp(fg.nf);
+    if (hipMemcpy(hp.data(), probs, hp.size() * sizeof(FiltProb), hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int q = 0; q < fg.nf; ++q) {
+        FiltState st;
+        if (hipMemcpy(&st, hp[q].st, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) break;
+        const double rp = hp[q].rp, np = hp[q].Npad, r32 = hp[q].r32;
+        const double stages = st.stage;
+        tm->gemm_flops += 2.0 * rp * np * np * st.products          // block products with G
+                          + 2.0 * rp * rp * np * (stages + 2 + 1)    // Gram of every CholQR (+ stage 0, polish) and H
+                          + 2.0 * r32 * np * np;                     // residuals of the Ritz pairs
+      }
+    }
+  }
   if (debug) {
     fprintf(stderr, "[tadmm] filter: %d of %d problems fall back to the full solve\n", bad, fg.nf);
     std::vector<FiltProb> hp(fg.nf);

@@ -186,6 +186,7 @@ struct tadmm_plan_s {
   int max_global_sweeps = 40;
   // filtered eigen-solver statistics of the last run
   int filt_problems = 0, filt_fallbacks = 0, filt_stages = 0;
+  FilterTiming ftm;
 };
 
 namespace {
@@ -725,6 +726,9 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
   double acc_ms[8] = {0};
   int total_sweeps = 0;
   p->filt_problems = p->filt_fallbacks = p->filt_stages = 0;
+  p->ftm.on = p->timing;
+  p->ftm.gemm_ms = 0.0; p->ftm.gemm_launches = 0; p->ftm.gemm_flops = 0.0;
+  if (p->timing) { p->ftm.a = p->ev[14]; p->ftm.b = p->ev[15]; }
   // timing helper: record a pair of events around a phase and accumulate after a sync
   auto tic = [&](int i) { if (p->timing) (void)hipEventRecord(p->ev[i], s); };
   auto toc = [&](int i, int slot) {
@@ -752,7 +756,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
     tic(0);
     const bool filtered = sp.fg.nf > 0;
     if (filtered) {
-      const int rc = filter_run_pre(h, sp.fg, ws, p->poll, s, p->debug);
+      const int rc = filter_run_pre(h, sp.fg, ws, p->poll, s, p->debug, &p->ftm);
       if (rc != TADMM_OK) return rc;
     }
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
@@ -786,7 +790,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
         small_pending = false;
       }
       int nbad = 0;
-      int rc = filter_run_post(h, sp.fg, ws, p->poll, s, p->debug, &nbad);
+      int rc = filter_run_post(h, sp.fg, ws, p->poll, s, p->debug, &nbad, &p->ftm);
       if (rc != TADMM_OK) return rc;
       p->filt_problems += sp.fg.nf;
       p->filt_fallbacks += nbad;
@@ -853,6 +857,12 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
   hipStream_t s = (hipStream_t)stream_;
   HIP_OK(p->h, hipMemcpyAsync(out_host, p->ws + off, (size_t)g.steps[step].r * 8, hipMemcpyDeviceToHost, s));
   HIP_OK(p->h, hipStreamSynchronize(s));
+  return TADMM_OK;
+}
+
+int tadmm_plan_filter_timing(tadmm_plan p, double out[4]) {
+  if (!p || !out) return TADMM_ERR_INVALID;
+  out[0] = p->ftm.gemm_ms; out[1] = p->ftm.gemm_launches; out[2] = p->ftm.gemm_flops; out[3] = 0.0;
   return TADMM_OK;
 }
 

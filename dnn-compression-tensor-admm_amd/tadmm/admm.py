@@ -4,8 +4,9 @@ Differences a caller can observe (all deliberate):
   * the projection of ALL layers runs as one grouped plan on the device -- no D2H/H2D round trip
     (admm.py:50-67) and no per-layer Python loop;
   * `self.z[name]` is updated in place instead of being re-bound to a new tensor each call;
-  * with `process_group` given, layers are sharded over the ranks (LPT on the SVD cost model) and Z
-    is re-assembled with one all-gather; the reference repeats the full projection on every rank.
+  * with `process_group` given, layers are sharded over the ranks (latency-aware partition, sched.py) and
+    Z / U / the residuals are re-assembled with ONE flat all-gather; the reference repeats the full projection on
+    every rank.
 """
 from __future__ import annotations
 
@@ -120,8 +121,11 @@ class ADMM:
         if self.process_group is not None and torch.distributed.get_world_size(self.process_group) > 1:
             ws = torch.distributed.get_world_size(self.process_group)
             rk = torch.distributed.get_rank(self.process_group)
-            costs = [sched.layer_cost(L["kind"], list(L["W"].shape), L.get("tt_shapes"), L["ranks"]) for L in layers]
-            parts = sched.lpt_partition(costs, ws)
+            # latency-aware split: a layer's chain of eigen-solves is latency-bound and layers on one rank share
+            # their launches, so ranks are balanced on the modelled level-by-level time, not on FLOPs (sched.py)
+            prof = [sched.layer_latency_profile(L["kind"], list(L["W"].shape), L.get("tt_shapes"), L["ranks"])
+                    for L in layers]
+            parts = sched.latency_partition(prof, ws)
             self._parts = parts
             self._owned = parts[rk]
         self._plan = ops.ProjectionPlan([layers[i] for i in self._owned]) if self._owned else None
@@ -154,7 +158,7 @@ class ADMM:
         if self._tk_names:
             resid.update(self._tk.run(update_u))
         if self.process_group is not None and torch.distributed.get_world_size(self.process_group) > 1:
-            self._exchange(update_u)
+            resid = self._exchange(update_u, resid)
         if update_u:
             for name, _ in named:                                               # admm.py:75-78
                 if name not in resid:
@@ -164,17 +168,53 @@ class ADMM:
                 if self.verbose:
                     print('*INFO: {} in ADMM, norm(w-z)={}'.format(name, resid[name]))
 
-    def _exchange(self, update_u):
-        """Sharded mode: broadcast each owner's Z (and U) so every rank holds the full state."""
+    def _exchange(self, update_u, resid):
+        """Sharded mode: ONE all-gather re-assembles the state -- every rank packs the Z (and U) of the layers it
+        owns plus their residuals into a flat buffer, the buffers are gathered, and every rank unpacks the layers
+        it does not own.  Returns the residuals of ALL layers (so every rank logs what the reference logs)."""
         dist = torch.distributed
+        ws = dist.get_world_size(self.process_group)
+        rk = dist.get_rank(self.process_group)
+        fields = [self.z, self.u] if update_u else [self.z]
+        def seg_len(part):      # floats: tensors, then (hi, lo) float pairs of the float64 residuals
+            return sum(self.z[self._names[i]].numel() for i in part) * len(fields) + 2 * len(part)
+        mx = max(1, max(seg_len(p) for p in self._parts))
+        send = torch.zeros(mx, dtype=torch.float32, device=self.device)
+        off = 0
+        mine = self._parts[rk]
+        for f in fields:
+            for i in mine:
+                t = f[self._names[i]]
+                send[off:off + t.numel()].copy_(t.reshape(-1))
+                off += t.numel()
+        if mine:
+            r64 = torch.tensor([float(resid.get(self._names[i], 0.0)) for i in mine], dtype=torch.float64)
+            hi = r64.float()
+            lo = (r64 - hi.double()).float()
+            send[off:off + len(mine)].copy_(hi)
+            send[off + len(mine):off + 2 * len(mine)].copy_(lo)
+        recv = torch.empty(ws * mx, dtype=torch.float32, device=self.device)
+        try:
+            dist.all_gather_into_tensor(recv, send, group=self.process_group)
+        except (RuntimeError, NotImplementedError):      # backends without the flat form: same data, list form
+            chunks = list(recv.split(mx))
+            dist.all_gather(chunks, send, group=self.process_group)
+        out = dict(resid)
         for owner, part in enumerate(self._parts):
-            for i in part:
-                name = self._names[i]
-                dist.broadcast(self.z[name], src=dist.get_global_rank(self.process_group, owner),
-                               group=self.process_group)
-                if update_u:
-                    dist.broadcast(self.u[name], src=dist.get_global_rank(self.process_group, owner),
-                                   group=self.process_group)
+            seg = recv[owner * mx:(owner + 1) * mx]
+            off = 0
+            for f in fields:
+                for i in part:
+                    t = f[self._names[i]]
+                    if owner != rk:
+                        t.copy_(seg[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+            if part:         # (the owner too: every rank logs the same transported value, bit for bit)
+                hi = seg[off:off + len(part)].double().cpu()
+                lo = seg[off + len(part):off + 2 * len(part)].double().cpu()
+                for j, i in enumerate(part):
+                    out[self._names[i]] = float(hi[j] + lo[j])
+        return out
 
     def append_admm_loss(self, loss):
         params = [p for _, p in self._named()]

@@ -117,6 +117,12 @@ class ProjectionPlan:
         self.h.check(self.h.lib.tadmm_plan_filter_stats(self._plan, out))
         return dict(eligible=int(out[0]), solves=int(out[1]), fallbacks=int(out[2]), stages=int(out[3]))
 
+    def filter_timing(self) -> dict:
+        """Instrumented runs: summed duration, count and executed FLOPs of the filter's fp64 GEMM launches."""
+        out = (C.c_double * 4)()
+        self.h.check(self.h.lib.tadmm_plan_filter_timing(self._plan, out))
+        return dict(gemm_ms=float(out[0]), gemm_launches=int(out[1]), gemm_flops=float(out[2]))
+
     def singular_values(self, layer: int, step: int) -> np.ndarray:
         r = self.ranks[layer][step + 1]
         out = (C.c_double * r)()

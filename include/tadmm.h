@@ -122,6 +122,11 @@ int tadmm_plan_set_jacobi(tadmm_plan p, double tol, int inner_sweeps, int max_sw
  * solve, out[3] = largest number of filter stages a level needed.  TADMM_FILTER=0 in the environment disables the
  * path (every problem takes the full solve). */
 int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]);
+/* With timing enabled (tadmm_plan_enable_timing) the fp64 GEMM launches of the filtered eigen-solver
+ * (dgemm_nt_tile_kernel: block products, Gram matrices, Rayleigh-Ritz projection, residuals) are timed one by one
+ * with HIP events on the launch stream: out[0] = their summed duration in ms, out[1] = number of launches,
+ * out[2] = floating-point operations they executed (2*M*N*K of every product that was not gated off). */
+int tadmm_plan_filter_timing(tadmm_plan p, double out[4]);
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
 int tadmm_plan_destroy(tadmm_plan p);

@@ -1,5 +1,12 @@
 """Condense rocprofv3 output (kernel stats + FETCH_SIZE / WRITE_SIZE passes) into a markdown summary."""
-import csv, glob, os, sys, collections, json
+import csv, glob, os, re, sys, collections, json
+
+
+def norm(n):
+    """kernel name without return type, namespace, template arguments and parameter list"""
+    n = n.split("(")[0].replace("tadmm::", "").replace("void ", "")
+    return re.sub(r"<.*>", "", n).strip()
+
 
 out = sys.argv[1]
 
@@ -21,7 +28,7 @@ if st:
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
     for row in csv.DictReader(open(st)):
-        name = row["Name"].split("(")[0].replace("tadmm::", "")
+        name = norm(row["Name"])
         if len(name) > 60: name = name[:57] + "..."
         print("| %s | %s | %.3f | %.2f | %s |" % (name, row["Calls"], float(row["TotalDurationNs"]) / 1e6, float(row["AverageNs"]) / 1e3, row["Percentage"]))
 for tag, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
@@ -31,7 +38,7 @@ for tag, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE
     acc = collections.defaultdict(lambda: [0, 0.0])
     for row in csv.DictReader(open(f)):
         if row.get("Counter_Name") != tag: continue
-        name = row["Kernel_Name"].split("(")[0].replace("tadmm::", "")
+        name = norm(row["Kernel_Name"])
         a = acc[name]; a[0] += 1; a[1] += float(row["Counter_Value"])
     print("\n## %s per launch (raw counter, KiB; FETCH_SIZE under-reports wide streaming reads by 2x on gfx950)\n" % tag)
     print("| kernel | launches | avg per launch (KiB) | total (MiB) |")
@@ -45,7 +52,7 @@ fm = find("pmc_mfma/**/*counter_collection.csv")
 if fm:
     acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for row in csv.DictReader(open(fm)):
-        name = row["Kernel_Name"].split("(")[0].replace("tadmm::", "")
+        name = norm(row["Kernel_Name"])
         a = acc[name]
         if row.get("Counter_Name") == "SQ_VALU_MFMA_BUSY_CYCLES":
             a[0] += 1; a[1] += float(row["Counter_Value"])
@@ -66,14 +73,14 @@ if ff and fw:
         acc = collections.defaultdict(lambda: [0, 0.0])
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != tag: continue
-            name = row["Kernel_Name"].split("(")[0].replace("tadmm::", "")
+            name = norm(row["Kernel_Name"])
             a = acc[name]; a[0] += 1; a[1] += float(row["Counter_Value"])
         for name, (n, tot) in acc.items():
             per[name][tag + "_KiB_per_launch_raw"] = tot / n
             per[name]["launches"] = n
     for name, d in per.items():
         d["hbm_bytes_per_launch_corrected"] = (2 * d.get("FETCH_SIZE_KiB_per_launch_raw", 0.0) + d.get("WRITE_SIZE_KiB_per_launch_raw", 0.0)) * 1024
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1, ResNet-50 TT",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --no-per-layer, ResNet-50 TT",
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (FETCH_SIZE counts 64 B per 128-B request on gfx950)",
-               "kernels": {k: v for k, v in per.items() if not k.startswith("void at::") and not k.startswith("__amd")}},
+               "kernels": {k: v for k, v in per.items() if not k.startswith("at::") and not k.startswith("__amd")}},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
