@@ -280,7 +280,7 @@ static inline FiltParams filter_params(const FilterGroup& fg) {
   prm.max_degree = fg.max_degree;
   prm.log_target = log(2.0 / 1e-11);
   prm.cond_max = 1e6;
-  prm.sin_tol = 5e-6;
+  prm.sin_tol = 1e-5;
   if (const char* e = getenv("TADMM_FILTER_EPS")) prm.log_target = log(2.0 / atof(e));
   if (const char* e = getenv("TADMM_FILTER_COND")) prm.cond_max = atof(e);
   if (const char* e = getenv("TADMM_FILTER_SINTOL")) prm.sin_tol = atof(e);
