@@ -34,6 +34,21 @@ namespace tadmm {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Every C-ABI entry that launches or allocates runs on the handle's device, whatever device the calling thread
+// has current (one process may drive several GPUs); the caller's choice is restored on exit.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const tadmm_ctx_s* h) {
+    if (!h) return;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+    if (prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct Phase {  // one grouped launch: descriptor array + block map inside the device arena
   size_t desc_off = 0, map_off = 0;
   int nprob = 0, nblocks = 0;
@@ -235,6 +250,10 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
       }
     }
     launch_jacobi_conv(g.ed, g.neig, tick, tol, g.mode >= 1, g.prev_dev, poll.host + (size_t)(gs & 1) * poll.stride, s);
+    {   // a failed launch (LDS attribute not set on this device, bad configuration) must surface, not spin to max_sweeps
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) CTX_FAIL(h, TADMM_ERR_HIP, "Jacobi launch failed: %s", hipGetErrorString(le));
+    }
     if (debug && g.off_dev) {
       h_off.resize((size_t)g.neig * 3); h_done.resize(g.neig);
       HIP_OK(h, hipMemcpyAsync(h_off.data(), g.off_dev, (size_t)g.neig * 3 * 8, hipMemcpyDeviceToHost, s));

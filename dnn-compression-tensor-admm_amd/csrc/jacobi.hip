@@ -1154,7 +1154,10 @@ bool jacobi_tick3_fits(int ld_max) { return jacobi_tick3_lds_bytes(ld_max) <= 16
 void launch_jacobi_tick3(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                          int ld_max, hipStream_t s) {
   if (nblocks <= 0) return;
-  static bool attr_set = false;
+  static bool attr_done[64] = {false};       // per device: the attribute belongs to the device's code object
+  int devi = 0;
+  (void)hipGetDevice(&devi);
+  bool& attr_set = attr_done[devi & 63];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1174,7 +1177,10 @@ bool jacobi_tick2_fits(int ld_max) { return jacobi_tick2_lds_bytes(ld_max) <= 16
 void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, int ld_max, hipStream_t s) {
   if (nblocks <= 0) return;
-  static bool attr_set = false;
+  static bool attr_done[64] = {false};
+  int devi = 0;
+  (void)hipGetDevice(&devi);
+  bool& attr_set = attr_done[devi & 63];
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1188,7 +1194,10 @@ void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int n
 void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, size_t lds_bytes, bool super, hipStream_t s) {
   if (nblocks <= 0) return;
-  static bool attr_set = false;
+  static bool attr_done[64] = {false};
+  int devi = 0;
+  (void)hipGetDevice(&devi);
+  bool& attr_set = attr_done[devi & 63];
   if (!attr_set) {   // allow the full 160 KiB of a CU as dynamic LDS (default cap is 64 KiB)
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -655,6 +655,7 @@ int tadmm_plan_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_d
 int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
                       float* const* U, float* const* Z, float* const* cores, void* workspace, size_t workspace_bytes,
                       tadmm_plan* out) {
+  DeviceGuard device_guard(h);
   if (!h || !descs || !W || !U || !Z || !workspace || !out || n_layers <= 0) return TADMM_ERR_INVALID;
   tadmm_plan_s* P = new tadmm_plan_s();
   P->h = h;
@@ -701,6 +702,7 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
 }
 
 int tadmm_plan_enable_timing(tadmm_plan p, int on) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_ERR_INVALID;
   if (on && !p->ev_made) {
     for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) return TADMM_ERR_HIP;
@@ -718,6 +720,7 @@ int tadmm_plan_last_timing(tadmm_plan p, double out_ms[8]) {
 }
 
 int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_ERR_INVALID;
   tadmm_handle h = p->h;
   hipStream_t s = (hipStream_t)stream_;
@@ -849,6 +852,7 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
 }
 
 int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_host, void* stream_) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p || !out_host || layer < 0 || layer >= p->n) return TADMM_ERR_INVALID;
   const LayerGeom& g = p->layers[layer];
   if (step < 0 || step >= (int)g.steps.size()) return TADMM_ERR_INVALID;
@@ -875,6 +879,7 @@ int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]) {
 }
 
 int tadmm_plan_destroy(tadmm_plan p) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_OK;
   if (p->ev_made) for (auto& e : p->ev) (void)hipEventDestroy(e);
   p->poll.destroy();
@@ -902,6 +907,7 @@ int tadmm_penalty_scratch_doubles(void) { return kPenaltyBlocks; }
 
 int tadmm_penalty(tadmm_handle h, int n, const void* const* ptrs_dev, const int64_t* numel_dev, int64_t total_numel,
                   float rho, float grad_scale, double* loss_dev, double* partial_dev, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || n <= 0 || !ptrs_dev || !numel_dev || !loss_dev || !partial_dev) return TADMM_ERR_INVALID;
   launch_penalty(n, ptrs_dev, numel_dev, total_numel, rho, grad_scale, loss_dev, partial_dev, (hipStream_t)stream_);
   HIP_OK(h, hipGetLastError());
@@ -941,6 +947,7 @@ int tadmm_gemm_pack(int n, const tadmm_gemm_desc* descs, void* blob_host, size_t
 }
 
 int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !blob_dev || n <= 0 || nblocks <= 0) return TADMM_ERR_INVALID;
   const GemmDesc* gd = (const GemmDesc*)blob_dev;
   const BlockRef* map = (const BlockRef*)((const char*)blob_dev + align_up((size_t)n * sizeof(GemmDesc), 256));
@@ -950,6 +957,7 @@ int tadmm_gemm_run(tadmm_handle h, const void* blob_dev, int n, int nblocks, voi
 }
 
 int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* sdesc, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !sdesc) return TADMM_ERR_INVALID;
   const tadmm_gemm_desc& s = *sdesc;
   if (s.M <= 0 || s.N <= 0 || s.K <= 0 || !s.A || !s.B || !s.C) CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_gemm: empty operand");
@@ -969,6 +977,7 @@ int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* sdesc, void* stream_) {
 
 int tadmm_gemm_bf16_nt(tadmm_handle h, const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda,
                        int64_t ldb, int64_t ldc, const float* bias_n, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !A || !Bt || !C) return TADMM_ERR_INVALID;
   if (M <= 0 || N <= 0 || K <= 0 || lda < K || ldb < K || ldc < N) CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_gemm_bf16_nt: bad shape");
   launch_gemm_bf16_nt(A, Bt, C, M, N, K, lda, ldb, ldc, bias_n, (hipStream_t)stream_);
@@ -1013,6 +1022,7 @@ int tadmm_gram_ld(int m, int n, int* Npad, int* ld) {
 
 int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int ldg, void* scratch, size_t scratch_bytes,
                    void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !A || !G || !scratch || m <= 0 || n <= 0) return TADMM_ERR_INVALID;
   StepGeom st;
   gram_geom(m, n, st);
@@ -1052,6 +1062,7 @@ size_t tadmm_eigh_scratch_bytes(int N) {
 
 int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, double* evecs_out, void* scratch,
                    size_t scratch_bytes, int* sweeps_out, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !G || !evals_out || !evecs_out || !scratch || N <= 0) return TADMM_ERR_INVALID;
   if (scratch_bytes < tadmm_eigh_scratch_bytes(N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "eigh scratch too small");
   hipStream_t s = (hipStream_t)stream_;
@@ -1138,6 +1149,7 @@ size_t tadmm_dgemm_scratch_bytes(int M, int N) {
 
 int tadmm_dgemm_f64(tadmm_handle h, const double* A, const double* B, double* C, int M, int N, int K, int lda, int ldb,
                     int ldc, int b_transposed, void* scratch, size_t scratch_bytes, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !A || !B || !C || !scratch) return TADMM_ERR_INVALID;
   if (M <= 0 || N <= 0 || K <= 0 || M % 32 || N % 32 || K % 16 || (lda & 1) || (ldb & 1) || (ldc & 1))
     CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_dgemm_f64: M, N multiples of 32, K of 16, even leading dimensions");
@@ -1176,6 +1188,7 @@ size_t tadmm_cholqr_scratch_bytes(int n, int ncols) {
 
 int tadmm_cholqr_f64(tadmm_handle h, double* YT, int n, int ncols, int ldy, void* scratch, size_t scratch_bytes,
                      int* bad_out_host, void* stream_) {
+  DeviceGuard device_guard(h);
   if (!h || !YT || !scratch || !bad_out_host) return TADMM_ERR_INVALID;
   if (n <= 0 || n > 256 || n % 32 || ncols <= 0 || ncols % 64 || ldy < ncols || (ldy & 1))
     CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_cholqr_f64: n multiple of 32 (<= 256), ncols multiple of 64, ldy >= ncols even");

@@ -433,6 +433,7 @@ int tadmm_tucker_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer
 int tadmm_tucker_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
                         float* const* U, float* const* Z, void* workspace, size_t workspace_bytes,
                         tadmm_tucker_plan* out) {
+  DeviceGuard device_guard(h);
   if (!h || !descs || !out || !W || !U || !Z || n_layers < 0) return TADMM_ERR_INVALID;
   tadmm_tucker_plan_s* P = new tadmm_tucker_plan_s;
   int rc = tucker_geom(h, n_layers, descs, P);
@@ -464,6 +465,7 @@ int tadmm_tucker_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* de
 }
 
 int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_ERR_INVALID;
   tadmm_handle h = p->h;
   hipStream_t s = (hipStream_t)stream_;
@@ -582,6 +584,7 @@ int tadmm_tucker_factors(tadmm_tucker_plan p, int layer, const float** core, con
 }
 
 int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double* errors_out_host, void* stream_) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream_;
   HIP_OK(p->h, hipStreamSynchronize(s));
@@ -599,6 +602,7 @@ int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double
 }
 
 int tadmm_tucker_destroy(tadmm_tucker_plan p) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_OK;
   p->poll.destroy();
   p->hooi.destroy();
