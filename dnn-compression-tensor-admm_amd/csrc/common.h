@@ -127,6 +127,18 @@ void launch_gemm_one(const GemmDesc& d, hipStream_t s);   // descriptor passed a
 void launch_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
                          int64_t ldc, const float* bias_n, hipStream_t s);
 
+// ---------------------------------------------------------------- forward chains of the factorised layers (chain.hip)
+struct ChainDesc {
+  const void* X; void* Y;
+  const uint16_t* Win; const uint16_t* Wout;    // bf16 planes in fragment-major order (chain.hip)
+  const float* bias;
+  int64_t T;
+  int32_t Kin, R, Nout;
+  int64_t ldx, ldy, win_plane, wout_plane;
+  int32_t x_hw, y_hw, x_vec, fused, dbg;
+};
+int launch_tt_chain(const ChainDesc& d, int dtype, int tile_tokens, hipStream_t s);
+
 // ---------------------------------------------------------------- grouped GEMM (fp64 MFMA) -- filtered eigen-solver
 // See dgemm.hip.  M, N multiples of 32, K multiple of 16; every leading dimension even (16-byte rows).
 struct DgemmDesc {

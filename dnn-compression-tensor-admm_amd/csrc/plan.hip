@@ -985,6 +985,49 @@ int tadmm_gemm_bf16_nt(tadmm_handle h, const void* A, const void* Bt, void* C, i
   return TADMM_OK;
 }
 
+// ---- forward chains of the factorised layers (chain.hip) ----
+static int chain_entry(tadmm_handle h, const tadmm_chain_desc* c, int fused, const char* who, void* stream_) {
+  DeviceGuard device_guard(h);
+  if (!h || !c) return TADMM_ERR_INVALID;
+  if (!c->X || !c->Y || !c->Win || (fused && !c->Wout)) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: null operand");
+  if (c->T < 0 || c->Kin <= 0 || c->R <= 0 || (fused && c->Nout <= 0)) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: bad shape");
+  if (c->dtype != TADMM_CHAIN_F32 && c->dtype != TADMM_CHAIN_BF16) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: bad dtype");
+  const int epl = c->dtype == TADMM_CHAIN_F32 ? 4 : 8;          // elements per 16-byte load of X
+  const int64_t ks1 = (c->Kin + 31) / 32, nt1 = (c->R + 15) / 16;
+  if ((((uintptr_t)c->Win) & 15) || c->win_plane < nt1 * ks1 * 512 || (c->win_plane & 7))
+    CTX_FAIL(h, TADMM_ERR_INVALID, "chain: Win planes must be 16-byte aligned fragment-major images of ceil(R/16) x ceil(Kin/32) KiB blocks");
+  if (c->x_hw == 0 && (c->ldx < c->Kin || c->Kin % epl || c->ldx % epl || (((uintptr_t)c->X) & 15)))
+    CTX_FAIL(h, TADMM_ERR_INVALID, "chain: X rows must be 16-byte aligned with Kin a whole number of 16-byte vectors");
+  if (c->y_hw == 0 && c->ldy < (fused ? c->Nout : c->R)) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: ldy too small");
+  if (c->x_hw < 0 || c->y_hw < 0) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: negative image size");
+  if (((uintptr_t)c->bias) & 15) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: bias must be 16-byte aligned");
+  if (fused) {
+    if (c->R % 32 || c->R > 256) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "chain: fused middle rank must be a multiple of 32, at most 256");
+    const int64_t nt2 = (c->Nout + 15) / 16;
+    if ((((uintptr_t)c->Wout) & 15) || c->wout_plane < nt2 * (c->R / 32) * 512 || (c->wout_plane & 7))
+      CTX_FAIL(h, TADMM_ERR_INVALID, "chain: Wout planes must be 16-byte aligned fragment-major images of ceil(Nout/16) x R/32 KiB blocks");
+  }
+  if (c->tile_tokens != 0 && c->tile_tokens != 32 && c->tile_tokens != 64) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: tile_tokens");
+  ChainDesc d;
+  memset(&d, 0, sizeof d);
+  d.X = c->X; d.Y = c->Y; d.Win = (const uint16_t*)c->Win; d.Wout = (const uint16_t*)c->Wout; d.bias = c->bias;
+  d.T = c->T; d.Kin = c->Kin; d.R = c->R; d.Nout = c->Nout;
+  d.ldx = c->ldx; d.ldy = c->ldy;
+  d.win_plane = c->win_plane; d.wout_plane = c->wout_plane;
+  d.x_hw = c->x_hw; d.y_hw = c->y_hw; d.fused = fused;
+  d.x_vec = (c->x_hw > 0 && c->x_hw % epl == 0 && (((uintptr_t)c->X) & 15) == 0) ? 1 : 0;
+  if (launch_tt_chain(d, c->dtype, c->tile_tokens, (hipStream_t)stream_) != 0)
+    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "chain: token tile does not fit the LDS");
+  HIP_OK(h, hipGetLastError());
+  (void)who;
+  return TADMM_OK;
+}
+int tadmm_ttlinear_fwd(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 1, "ttlinear_fwd", s); }
+int tadmm_ttlinear_bwd(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 1, "ttlinear_bwd", s); }
+int tadmm_ttconv_chain_in(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 0, "ttconv_chain_in", s); }
+int tadmm_ttconv_chain_out(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 0, "ttconv_chain_out", s); }
+int tadmm_tucker_1x1(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 0, "tucker_1x1", s); }
+
 // ---- standalone Gram / eigh (tests, Tucker path) ----
 static void gram_geom(int m, int n, StepGeom& st) {
   st.m = m; st.cols = n; st.trans = m > n;

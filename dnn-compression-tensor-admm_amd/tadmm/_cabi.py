@@ -56,6 +56,18 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ChainDesc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("Y", C.c_void_p), ("Win", C.c_void_p), ("Wout", C.c_void_p), ("bias", C.c_void_p),
+        ("T", C.c_int64),
+        ("Kin", C.c_int32), ("R", C.c_int32), ("Nout", C.c_int32),
+        ("ldx", C.c_int64), ("ldy", C.c_int64), ("win_plane", C.c_int64), ("wout_plane", C.c_int64),
+        ("x_hw", C.c_int32), ("y_hw", C.c_int32), ("dtype", C.c_int32), ("tile_tokens", C.c_int32),
+    ]
+
+
+CHAIN_F32, CHAIN_BF16 = 0, 1
+
 # name -> (restype, argtypes); this table IS the list of symbols include/tadmm.h declares
 ABI = {
     "tadmm_version": (C.c_int, []),
@@ -95,6 +107,11 @@ ABI = {
     "tadmm_gemm": (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_void_p]),
     "tadmm_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tadmm_ttlinear_fwd": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
+    "tadmm_ttlinear_bwd": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
+    "tadmm_ttconv_chain_in": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
+    "tadmm_ttconv_chain_out": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
+    "tadmm_tucker_1x1": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
     "tadmm_gram_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "tadmm_gram_ld": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tadmm_gram_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

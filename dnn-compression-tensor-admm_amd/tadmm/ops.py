@@ -312,6 +312,115 @@ def mm_nt_bf16(a: torch.Tensor, bt: torch.Tensor, bias_n: Optional[torch.Tensor]
     return out
 
 
+# ------------------------------------------------------------------ forward chains (csrc/chain.hip)
+def weight_planes(w: torch.Tensor, planes: int, pad_rows: int = 16) -> torch.Tensor:
+    """(N, K) weight -> (planes, Np/16, Kp/32, 64, 8) bfloat16 in the fragment-major order of csrc/chain.hip
+    (Kp = K rounded up to 32, Np = N rounded up to `pad_rows`, a multiple of 16; zero padded).
+    planes == 3: the exact three-term split w = w1 + w2 + w3 of a float32 weight; planes == 1: its bf16 rounding."""
+    assert w.dim() == 2 and planes in (1, 3) and pad_rows % 16 == 0
+    if not w.is_cuda:
+        raise TadmmError(-1, "weights must live on a HIP device; there is no CPU path")
+    N, K = w.shape
+    Np, Kp = -(-N // pad_rows) * pad_rows, -(-K // 32) * 32
+    flat = torch.zeros(planes, Np, Kp, dtype=torch.bfloat16, device=w.device)
+    r = w.detach().float()
+    for p in range(planes):
+        t = r.to(torch.bfloat16)
+        flat[p, :N, :K] = t
+        if p + 1 < planes:
+            r = r - t.float()
+    # (p, n/16, n%16, k/32, (k%32)/8, k%8) -> (p, n/16, k/32, (k%32)/8, n%16, k%8)
+    return flat.view(planes, Np // 16, 16, Kp // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous().view(
+        planes, Np // 16, Kp // 32, 64, 8)
+
+
+def unpack_planes(wp: torch.Tensor) -> torch.Tensor:
+    """Inverse of `weight_planes`: (planes, Np, Kp) bfloat16 row-major (tests, debugging)."""
+    P, nt, ks = wp.shape[:3]
+    return wp.view(P, nt, ks, 4, 16, 8).permute(0, 1, 4, 2, 3, 5).reshape(P, nt * 16, ks * 32)
+
+
+def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin: int, n1: int, n_out: int,
+                image_out: bool, tile_tokens: int, prepare_only: bool = False):
+    if not x.is_cuda:
+        raise TadmmError(-1, "x must live on a HIP device; there is no CPU path")
+    if x.dtype == torch.float32:
+        dtype, planes = _cabi.CHAIN_F32, 3
+    elif x.dtype == torch.bfloat16:
+        dtype, planes = _cabi.CHAIN_BF16, 1
+    else:
+        raise TadmmError(-1, f"chain: unsupported dtype {x.dtype}")
+    if win.dtype != torch.bfloat16 or win.dim() != 5 or win.shape[0] != planes or not win.is_contiguous():
+        raise TadmmError(-1, f"chain: weights must be {planes} contiguous bf16 plane(s) (ops.weight_planes)")
+    d = _cabi.ChainDesc()
+    if x.dim() == 4:                                   # (B, C, H, W) read in place
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        assert Cc == kin
+        T, hw = B * H * W, H * W
+        d.x_hw, d.ldx = hw, 0
+    else:
+        assert x.dim() == 2 and x.shape[1] == kin
+        if x.stride(1) != 1 or (x.stride(0) * x.element_size()) % 16 or x.data_ptr() % 16:
+            x = x.contiguous()
+        T, hw = x.shape[0], 0
+        d.x_hw, d.ldx = 0, x.stride(0)
+    feat = n_out if wout is not None else n1
+    if image_out:
+        assert hw > 0
+        y = torch.empty(x.shape[0], feat, x.shape[2], x.shape[3], dtype=x.dtype, device=x.device)
+        d.y_hw, d.ldy = hw, 0
+    else:
+        y = torch.empty(T, feat, dtype=x.dtype, device=x.device)
+        d.y_hw, d.ldy = 0, feat
+    if bias is not None:
+        bias = bias.detach().float().contiguous()
+    d.X, d.Y, d.Win = x.data_ptr(), y.data_ptr(), win.data_ptr()
+    d.Wout = None if wout is None else wout.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.T, d.Kin, d.R, d.Nout = T, kin, n1, n_out if wout is not None else 0
+    if win.shape[2] != -(-kin // 32) or win.shape[1] * 16 < n1:
+        raise TadmmError(-1, "chain: weight planes do not match the operand shape")
+    d.win_plane = win[0].numel()
+    if wout is not None:
+        if wout.dtype != torch.bfloat16 or wout.dim() != 5 or wout.shape[0] != planes or not wout.is_contiguous():
+            raise TadmmError(-1, f"chain: weights must be {planes} contiguous bf16 plane(s) (ops.weight_planes)")
+        if wout.shape[2] * 32 != n1 or wout.shape[1] * 16 < n_out:
+            raise TadmmError(-1, "chain: output weight planes do not match the middle rank / output size")
+        d.wout_plane = wout[0].numel()
+    d.dtype, d.tile_tokens = dtype, tile_tokens
+    dev = x.device
+    h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    fn = getattr(h.lib, entry)
+    keep = (x, win, wout, bias, y)
+
+    def launch():
+        if T > 0:
+            h.check(fn(h.ptr, C.byref(d), _stream(dev)))
+        return keep[-1]
+
+    if prepare_only:
+        return launch
+    return launch()
+
+
+def chain_fused(x, win_planes, wout_planes, bias, n_out: int, entry: str = "tadmm_ttlinear_fwd", tile_tokens: int = 0,
+                prepare_only: bool = False):
+    """y (T, n_out) = (x (T, Kin) @ Win^T) @ Wout^T + bias in one launch (TTLinear.py:75-93).  `win_planes` (rows
+    padded to the middle rank R, a multiple of 32, <= 256) and `wout_planes` come from `weight_planes`."""
+    return _chain_call(entry, x, win_planes, wout_planes, bias, x.shape[-1], win_planes.shape[1] * 16, n_out, False,
+                       tile_tokens, prepare_only)
+
+
+def chain_single(x, w_planes, bias, n_out: int, entry: str = "tadmm_ttconv_chain_in", image_out: bool = False,
+                 tile_tokens: int = 0, prepare_only: bool = False):
+    """y = x @ W^T + bias for token rows (T, Kin) or, in place, a channels-first image (B, Kin, H, W) ->
+    (B, n_out, H, W) when `image_out` (TTConv.py:131-137 / :141-151, TKConv.py:93-98).  `prepare_only` returns a
+    zero-argument launcher over the same buffers (benchmarks: no per-call descriptor building)."""
+    kin = x.shape[1]
+    return _chain_call(entry, x, w_planes, None, bias, kin, n_out, 0, image_out, tile_tokens, prepare_only)
+
+
 # ------------------------------------------------------------------ Gram / eigh (tests, Tucker)
 def gram(a: torch.Tensor):
     """fp64 Gram of a float32 (m,n) matrix: A A^T if m<=n else A^T A.  Returns (N,N) float64."""

@@ -190,6 +190,43 @@ int tadmm_gemm(tadmm_handle h, const tadmm_gemm_desc* desc, void* stream);
 int tadmm_gemm_bf16_nt(tadmm_handle h, const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda,
                        int64_t ldb, int64_t ldc, const float* bias_n, void* stream);
 
+/* ---- forward chains of the factorised layers (csrc/chain.hip) ---------------------------------------------------
+ * One launch per chain on the bf16 matrix cores; the per-token intermediate stays in LDS.
+ *   fused  : Y[t][:] = Wout (Win X[t][:]) + bias     TTLinearM (TTLinear.py:75-93); Win (R x Kin) / Wout (Nout x R)
+ *            are the contracted input / output cores, R the middle TT rank (multiple of 32, <= 256; pad with zeros).
+ *   single : Y[t][:] = Win X[t][:] + bias            N = R output features, any size.
+ * dtype TADMM_CHAIN_F32: X, Y float32; weights as THREE bf16 planes (w = w1 + w2 + w3 exactly, plane p at
+ *   W + p * plane_stride); six bf16 products per fp32 product, fp32 accumulate: fp32-GEMM accuracy.
+ * dtype TADMM_CHAIN_BF16: X, Y bfloat16; one weight plane.
+ * Layouts: x_hw / y_hw == 0: token rows of ldx / ldy elements.  x_hw / y_hw > 0: channels-first images
+ *   (batch, channel, pixel) of that many pixels -- the NCHW tensors of TTConv.py:131 / TKConv.py:94 in place.
+ * Weights are FRAGMENT-MAJOR (one MFMA operand = one contiguous KiB): element (row n, col k) of plane p of an
+ *   N x K weight lives at W[p*plane + (((n/16)*KS + k/32)*64 + (k%32/8)*16 + n%16)*8 + k%8], KS = ceil(K/32), rows
+ *   padded to 16 and columns to 32 with zeros (tadmm.ops.weight_planes builds it).  Token rows: Kin % 8 == 0
+ *   (% 4 for float32) and 16-byte aligned rows.  bias: float32[N], 16-byte aligned, or NULL.  tile_tokens: 0 (default), 32 or 64. */
+enum { TADMM_CHAIN_F32 = 0, TADMM_CHAIN_BF16 = 1 };
+typedef struct {
+  const void* X; void* Y;
+  const void* Win; const void* Wout;          /* bf16 planes */
+  const float* bias;
+  int64_t T;                                   /* tokens (rows, or batch * pixels) */
+  int32_t Kin, R, Nout;
+  int64_t ldx, ldy, win_plane, wout_plane;   /* elements */
+  int32_t x_hw, y_hw;
+  int32_t dtype, tile_tokens;
+} tadmm_chain_desc;
+/* TTLinearM forward (TTLinear.py:75-93), fused. */
+int tadmm_ttlinear_fwd(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
+/* TTLinearM data gradient dX = (dY Wout) Win: the same fused kernel with X = dY, Win = Wout^T planes (R x Nout),
+ * Wout = Win^T planes (Kin x R); weight gradients are plain products (tadmm_gemm). */
+int tadmm_ttlinear_bwd(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
+/* TTConv2dM input-core chain (TTConv.py:131-137): image (B, C, H, W) -> (B, r, H, W), single product. */
+int tadmm_ttconv_chain_in(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
+/* TTConv2dM output-core chain + bias (TTConv.py:141-151): (B, r, H', W') -> (B, O, H', W'), single product. */
+int tadmm_ttconv_chain_out(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
+/* TKConv2dC first / last 1x1 stage (TKConv.py:93-98): per-pixel channel mixing, single product. */
+int tadmm_tucker_1x1(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
+
 /* G = A A^T (m<=n) or A^T A (m>n) of a row-major float32 m x n matrix, exact fp32 products
  * accumulated in fp64 on v_mfma_f64_16x16x4_f64.  G is written as double[Npad][ldg] (zero padded; see tadmm_gram_ld), N=min(m,n).
  * partial_dev: scratch of tadmm_gram_scratch_bytes(m,n). */

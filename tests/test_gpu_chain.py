@@ -1,0 +1,106 @@
+"""Forward-chain kernels (csrc/chain.hip) through the C ABI: fused TTLinearM chain and the single products of the
+TTConv2dM / TKConv2dC chains, fp32 (three-plane bf16 split) and bf16, against fp64 torch references.
+
+Tolerances: the fp32 mode must be as accurate as an fp32 GEMM -- error <= 2e-6 of the largest |output| at K <= 1536
+(measured ~3e-7; an fp32 `torch.mm` on the CPU gives ~6e-7 on the same data); the bf16 mode is bounded by the bf16
+rounding of inputs, the intermediate and the output (2^-8 each): 2e-2 of the largest |output|."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from tadmm import ops
+    return ops
+
+
+def _ref_fused(x, win, wout, bias):
+    y = (x.double() @ win.double().t()) @ wout.double().t()
+    return y + (bias.double() if bias is not None else 0)
+
+
+@pytest.mark.parametrize("T,kin,r,nout,tile", [
+    (12608, 384, 256, 1152, 0),      # DeiT-S qkv at the bench's token count
+    (12608, 384, 256, 1152, 64),
+    (197, 384, 96, 384, 0),          # ragged token tile, middle rank not a multiple of 64
+    (50, 72, 20, 40, 0),             # Kin, R, Nout all need padding (R padded to 32 by weight_planes)
+    (1, 1536, 256, 384, 0),          # one token, long K (DeiT-S fc2)
+])
+def test_fused_fp32_matches_fp64(T, kin, r, nout, tile):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(T + kin)
+    x = torch.randn(T, kin, generator=g).cuda()
+    win = (torch.randn(r, kin, generator=g) / kin ** 0.5).cuda()
+    wout = (torch.randn(nout, r, generator=g) / r ** 0.5).cuda()
+    bias = torch.randn(nout, generator=g).cuda()
+    wp_in = ops.weight_planes(win, 3, pad_rows=32)
+    wp_out = ops.weight_planes(wout, 3)
+    assert wp_out.shape[2] * 32 == wp_in.shape[1] * 16
+    # the three planes reproduce the fp32 weight exactly
+    assert torch.equal(ops.unpack_planes(wp_in).float().sum(0)[:r, :kin], win)
+    y = ops.chain_fused(x, wp_in, wp_out, bias, nout, tile_tokens=tile)
+    ref = _ref_fused(x, win, wout, bias)
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert y.shape == (T, nout) and err < 2e-6, err
+    y2 = ops.chain_fused(x, wp_in, wp_out, None, nout, tile_tokens=tile)
+    torch.testing.assert_close(y2 + bias, y, atol=1e-6 * ref.abs().max().item(), rtol=0)
+
+
+@pytest.mark.parametrize("T,kin,r,nout,tile", [(12608, 384, 256, 1152, 0), (12608, 384, 256, 1152, 32), (77, 64, 32, 24, 0)])
+def test_fused_bf16(T, kin, r, nout, tile):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(T, kin, generator=g).cuda().bfloat16()
+    win = (torch.randn(r, kin, generator=g) / kin ** 0.5).cuda()
+    wout = (torch.randn(nout, r, generator=g) / r ** 0.5).cuda()
+    bias = torch.randn(nout, generator=g).cuda()
+    wp_in, wp_out = ops.weight_planes(win, 1, pad_rows=32), ops.weight_planes(wout, 1)
+    y = ops.chain_fused(x, wp_in, wp_out, bias, nout, tile_tokens=tile)
+    assert y.dtype == torch.bfloat16
+    ref = _ref_fused(x.float(), ops.unpack_planes(wp_in)[0, :r, :kin].float(), ops.unpack_planes(wp_out)[0, :nout, :r].float(), bias)
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("B,c,hw,n,img_out", [
+    (4, 64, (14, 14), 40, True),       # vectorised image loads (196 % 4 == 0)
+    (3, 48, (7, 7), 36, True),         # 49 pixels: scalar loads, images straddle token tiles
+    (2, 512, (7, 7), 300, False),      # more than 256 output features: two feature blocks
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_single_product_on_images(B, c, hw, n, img_out, dtype):
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(B * c + n)
+    x = torch.randn(B, c, *hw, generator=g).cuda().to(dtype)
+    w = (torch.randn(n, c, generator=g) / c ** 0.5).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    planes = 3 if dtype == torch.float32 else 1
+    wp = ops.weight_planes(w, planes)
+    y = ops.chain_single(x, wp, bias, n, image_out=img_out)
+    wq = ops.unpack_planes(wp).float().sum(0)[:n, :c].double()
+    ref = torch.einsum("bchw,nc->bnhw", x.double(), wq) + bias.double().view(1, -1, 1, 1)
+    if not img_out:
+        ref = ref.permute(0, 2, 3, 1).reshape(-1, n)
+    assert y.shape == ref.shape
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (2e-6 if dtype == torch.float32 else 1e-2), err
+
+
+def test_single_product_rows_to_rows_and_errors():
+    ops = _ops()
+    from tadmm._cabi import TadmmError
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(300, 96, generator=g).cuda()
+    w = torch.randn(520, 96, generator=g).cuda()
+    wp = ops.weight_planes(w, 3)
+    y = ops.chain_single(x, wp, None, 520, entry="tadmm_tucker_1x1")
+    ref = x.double() @ w.double().t()
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    # fused middle rank above the LDS-resident limit is refused, loudly
+    big = ops.weight_planes(torch.randn(288, 96, generator=g).cuda(), 3, pad_rows=32)
+    out = ops.weight_planes(torch.randn(64, 288, generator=g).cuda(), 3)
+    with pytest.raises(TadmmError):
+        ops.chain_fused(x, big, out, None, 64)
+    with pytest.raises(TadmmError):
+        ops.chain_fused(x.cpu(), wp, wp, None, 64)
