@@ -135,7 +135,8 @@ struct ChainDesc {
   int64_t T;
   int32_t Kin, R, Nout;
   int64_t ldx, ldy, win_plane, wout_plane;
-  int32_t x_hw, y_hw, x_vec, fused, dbg;
+  int32_t x_hw, y_hw, x_vec, y_vec, fused;
+  long long* stamps;                            // debugging: per-workgroup cycle stamps (nullable)
 };
 int launch_tt_chain(const ChainDesc& d, int dtype, int tile_tokens, hipStream_t s);
 

@@ -1002,7 +1002,7 @@ static int chain_entry(tadmm_handle h, const tadmm_chain_desc* c, int fused, con
   if (c->x_hw < 0 || c->y_hw < 0) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: negative image size");
   if (((uintptr_t)c->bias) & 15) CTX_FAIL(h, TADMM_ERR_INVALID, "chain: bias must be 16-byte aligned");
   if (fused) {
-    if (c->R % 32 || c->R > 256) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "chain: fused middle rank must be a multiple of 32, at most 256");
+    if (c->R % 64 || c->R > 256) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "chain: fused middle rank must be a multiple of 64, at most 256");
     const int64_t nt2 = (c->Nout + 15) / 16;
     if ((((uintptr_t)c->Wout) & 15) || c->wout_plane < nt2 * (c->R / 32) * 512 || (c->wout_plane & 7))
       CTX_FAIL(h, TADMM_ERR_INVALID, "chain: Wout planes must be 16-byte aligned fragment-major images of ceil(Nout/16) x R/32 KiB blocks");
@@ -1016,6 +1016,9 @@ static int chain_entry(tadmm_handle h, const tadmm_chain_desc* c, int fused, con
   d.win_plane = c->win_plane; d.wout_plane = c->wout_plane;
   d.x_hw = c->x_hw; d.y_hw = c->y_hw; d.fused = fused;
   d.x_vec = (c->x_hw > 0 && c->x_hw % epl == 0 && (((uintptr_t)c->X) & 15) == 0) ? 1 : 0;
+  const int nfeat = fused ? c->Nout : c->R;
+  if (c->y_hw > 0) d.y_vec = (c->y_hw % epl == 0 && (((uintptr_t)c->Y) & 15) == 0) ? 1 : 0;
+  else d.y_vec = (c->ldy % epl == 0 && nfeat % epl == 0 && (((uintptr_t)c->Y) & 15) == 0) ? 1 : 0;
   if (launch_tt_chain(d, c->dtype, c->tile_tokens, (hipStream_t)stream_) != 0)
     CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "chain: token tile does not fit the LDS");
   HIP_OK(h, hipGetLastError());

@@ -58,3 +58,130 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> 
     lead = x.shape[:-1]
     y = mm(x.reshape(-1, x.shape[-1]), weight.t(), bias)
     return y.reshape(*lead, weight.shape[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Forward chains on the bf16 matrix cores (csrc/chain.hip): one launch per chain, the per-token intermediate of the
+# fused TT-linear chain stays in LDS.  float32 tensors go through the exact three-plane bf16 split (fp32-GEMM
+# accuracy), bfloat16 tensors through one plane.
+# ---------------------------------------------------------------------------------------------------------------
+def planes_of(w: torch.Tensor, nplanes: int, pad_rows: int = 16, pad_cols: int = 32, transpose: bool = False,
+              cache: dict = None, tag=None):
+    """Fragment-major bf16 planes of a 2-D weight (`ops.weight_planes`).  With `cache` (a dict owned by the layer) the
+    packing is reused until the weight's version counter changes -- inference packs a layer once."""
+    key = None
+    if cache is not None:
+        key = (tag, w._version, tuple(w.shape), nplanes, pad_rows, pad_cols, transpose)
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+    src = w.detach()
+    wp = ops.weight_planes(src.t() if transpose else src, nplanes, pad_rows, pad_cols)
+    if cache is not None:
+        for k in [k for k in cache if k[0] == tag and k[3:] == key[3:]]:
+            del cache[k]                                            # older versions of the same weight
+        cache[key] = wp
+    return wp
+
+
+def _nplanes(x: torch.Tensor) -> int:
+    if x.dtype == torch.float32:
+        return 3
+    if x.dtype == torch.bfloat16:
+        return 1
+    raise TadmmError(-1, f"chain kernels take float32 or bfloat16 activations (got {x.dtype})")
+
+
+def fused_rank_ok(r: int) -> bool:
+    """The fused chain keeps a token's middle-rank vector in LDS: ranks up to 256 (padded to a multiple of 64)."""
+    return 0 < r <= 256
+
+
+class _ChainSingle(torch.autograd.Function):
+    """y = x W^T + bias on token rows (T, K) or, in place, on channels-first images (B, K, H, W) -> (B, N, H, W)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, entry, wp):
+        if not x.is_cuda:
+            raise TadmmError(-1, "chain operands must live on the HIP device (no CPU fallback)")
+        image = x.dim() == 4
+        if wp is None:
+            wp = planes_of(w, _nplanes(x))
+        y = ops.chain_single(x, wp, bias, w.shape[0], entry=entry, image_out=image)
+        ctx.save_for_backward(x, w)
+        ctx.entry, ctx.has_bias, ctx.image = entry, bias is not None, image
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:                 # dX = dY W : the same kernel with the transposed weight
+            gx = ops.chain_single(g, planes_of(w, _nplanes(g), transpose=True), None, w.shape[1], entry=ctx.entry,
+                                  image_out=ctx.image)
+        if ctx.needs_input_grad[1]:                 # dW = dY^T X  (N x K), plain fp32 product
+            if ctx.image:
+                g2 = g.permute(1, 0, 2, 3).reshape(g.shape[1], -1)
+                x2 = x.permute(1, 0, 2, 3).reshape(x.shape[1], -1)
+                gw = ops.mm(_as_gemm_operand(g2.float()), _as_gemm_operand(x2.float()).t())
+            else:
+                gw = ops.mm(_as_gemm_operand(g.float()).t(), _as_gemm_operand(x.float()))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3)) if ctx.image else g.sum(0)
+        return gx, gw, gb, None, None
+
+
+def pointwise(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, entry: str = "tadmm_tucker_1x1",
+              planes: torch.Tensor = None):
+    """Per-token / per-pixel linear map `x W^T + bias` with W (N, K): rows (..., K) or an image (B, K, H, W) in place
+    (the 1x1 convolutions of TKConv.py:93-98 and the core chains of TTConv.py:131-151).  Differentiable.  `planes`:
+    prebuilt `planes_of(w, ...)` (inference caches)."""
+    if x.dim() == 4:
+        return _ChainSingle.apply(x.contiguous(), w, bias, entry, planes)
+    lead = x.shape[:-1]
+    return _ChainSingle.apply(x.reshape(-1, x.shape[-1]), w, bias, entry, planes).reshape(*lead, w.shape[0])
+
+
+class _ChainFused(torch.autograd.Function):
+    """y = (x Win^T) Wout^T + bias in one launch; Win (R, K), Wout (N, R), R <= 256."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, w_out, bias, planes):
+        if not x.is_cuda:
+            raise TadmmError(-1, "chain operands must live on the HIP device (no CPU fallback)")
+        n = _nplanes(x)
+        if planes is None:
+            planes = (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))
+        y = ops.chain_fused(x, planes[0], planes[1], bias, w_out.shape[0])
+        ctx.save_for_backward(x, w_in, w_out)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_in, w_out = ctx.saved_tensors
+        g = g.contiguous()
+        n = _nplanes(g)
+        gx = gwi = gwo = gb = None
+        if ctx.needs_input_grad[0]:                 # dX = (dY Wout) Win: the fused kernel on the transposed factors
+            gx = ops.chain_fused(g, planes_of(w_out, n, pad_rows=64, transpose=True),
+                                 planes_of(w_in, n, pad_cols=64, transpose=True), None, w_in.shape[1],
+                                 entry="tadmm_ttlinear_bwd")
+        if ctx.needs_input_grad[1]:                 # dWin = (dY Wout)^T X
+            gr = ops.chain_single(g, planes_of(w_out, n, transpose=True), None, w_out.shape[1])
+            gwi = ops.mm(_as_gemm_operand(gr.float()).t(), _as_gemm_operand(x.float()))
+        if ctx.needs_input_grad[2]:                 # dWout = dY^T (X Win^T)
+            h = ops.chain_single(x, planes_of(w_in, _nplanes(x)), None, w_in.shape[0])
+            gwo = ops.mm(_as_gemm_operand(g.float()).t(), _as_gemm_operand(h.float()))
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = g.sum(0)
+        return gx, gwi, gwo, gb, None
+
+
+def linear_chain(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor, bias: torch.Tensor = None, planes=None):
+    """(..., K) -> (..., N): x Win^T Wout^T + bias through the fused chain kernel (TTLinear.py:75-93 with the input
+    cores contracted into Win and the output cores into Wout).  Differentiable.  `planes`: prebuilt
+    (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))."""
+    lead = x.shape[:-1]
+    return _ChainFused.apply(x.reshape(-1, x.shape[-1]), w_in, w_out, bias, planes).reshape(*lead, w_out.shape[0])

@@ -313,15 +313,16 @@ def mm_nt_bf16(a: torch.Tensor, bt: torch.Tensor, bias_n: Optional[torch.Tensor]
 
 
 # ------------------------------------------------------------------ forward chains (csrc/chain.hip)
-def weight_planes(w: torch.Tensor, planes: int, pad_rows: int = 16) -> torch.Tensor:
+def weight_planes(w: torch.Tensor, planes: int, pad_rows: int = 16, pad_cols: int = 32) -> torch.Tensor:
     """(N, K) weight -> (planes, Np/16, Kp/32, 64, 8) bfloat16 in the fragment-major order of csrc/chain.hip
-    (Kp = K rounded up to 32, Np = N rounded up to `pad_rows`, a multiple of 16; zero padded).
+    (Kp = K rounded up to `pad_cols`, a multiple of 32; Np = N rounded up to `pad_rows`, a multiple of 16; zero
+    padded).  The fused chain wants its middle rank padded to 64: `pad_rows=64` for Win, `pad_cols=64` for Wout.
     planes == 3: the exact three-term split w = w1 + w2 + w3 of a float32 weight; planes == 1: its bf16 rounding."""
-    assert w.dim() == 2 and planes in (1, 3) and pad_rows % 16 == 0
+    assert w.dim() == 2 and planes in (1, 3) and pad_rows % 16 == 0 and pad_cols % 32 == 0
     if not w.is_cuda:
         raise TadmmError(-1, "weights must live on a HIP device; there is no CPU path")
     N, K = w.shape
-    Np, Kp = -(-N // pad_rows) * pad_rows, -(-K // 32) * 32
+    Np, Kp = -(-N // pad_rows) * pad_rows, -(-K // pad_cols) * pad_cols
     flat = torch.zeros(planes, Np, Kp, dtype=torch.bfloat16, device=w.device)
     r = w.detach().float()
     for p in range(planes):
@@ -407,7 +408,7 @@ def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin:
 def chain_fused(x, win_planes, wout_planes, bias, n_out: int, entry: str = "tadmm_ttlinear_fwd", tile_tokens: int = 0,
                 prepare_only: bool = False):
     """y (T, n_out) = (x (T, Kin) @ Win^T) @ Wout^T + bias in one launch (TTLinear.py:75-93).  `win_planes` (rows
-    padded to the middle rank R, a multiple of 32, <= 256) and `wout_planes` come from `weight_planes`."""
+    padded to the middle rank R, a multiple of 64, <= 256) and `wout_planes` come from `weight_planes`."""
     return _chain_call(entry, x, win_planes, wout_planes, bias, x.shape[-1], win_planes.shape[1] * 16, n_out, False,
                        tile_tokens, prepare_only)
 

@@ -98,13 +98,21 @@ class TKConv2dC(_TKConvBase):
             init.xavier_uniform_(p)
 
     def _stages(self, x):
-        # a 1x1 conv is a channel-mixing GEMM on the NHWC view: runs on the HIP grouped GEMM
-        b, _, h, w = x.shape
-        f1 = HF.linear(x.permute(0, 2, 3, 1), self.first_kernel.reshape(self.in_rank, self.in_channels))
-        f1 = f1.permute(0, 3, 1, 2)
-        f2 = F.conv2d(f1, self.core_kernel, None, self.stride, self.padding, self.dilation, self.groups)
-        f3 = HF.linear(f2.permute(0, 2, 3, 1), self.last_kernel.reshape(self.out_channels, self.out_rank), self.bias)
-        return f1, f2, f3.permute(0, 3, 1, 2)
+        # a 1x1 conv is a per-pixel channel mix: one chain-kernel launch on the NCHW tensor as it stands
+        # (`tadmm_tucker_1x1`: no NHWC copies, bias in the epilogue)
+        grad = torch.is_grad_enabled()
+        cache = None if grad else self.__dict__.setdefault("_plane_cache", {})
+        w1 = self.first_kernel.reshape(self.in_rank, self.in_channels)
+        w3 = self.last_kernel.reshape(self.out_channels, self.out_rank)
+        n = 1 if x.dtype == torch.bfloat16 else 3
+        p1 = None if grad else HF.planes_of(self.first_kernel.reshape(self.in_rank, self.in_channels), n, cache=cache,
+                                            tag="first")
+        f1 = HF.pointwise(x, w1, None, "tadmm_tucker_1x1", p1)
+        core = self.core_kernel if x.dtype == self.core_kernel.dtype else self.core_kernel.to(x.dtype)
+        f2 = F.conv2d(f1, core, None, self.stride, self.padding, self.dilation, self.groups)
+        p3 = None if grad else HF.planes_of(w3, n, cache=cache, tag="last")
+        f3 = HF.pointwise(f2, w3, self.bias, "tadmm_tucker_1x1", p3)
+        return f1, f2, f3
 
     def forward(self, x):
         return self._stages(x)[2]
@@ -160,9 +168,15 @@ class TKConv2dM(_TKConvBase):
             init.xavier_uniform_(p)
 
     def forward(self, x: Tensor) -> Tensor:                       # TKConv.py:210-214
-        out = HF.linear(x.permute(0, 2, 3, 1), self.first_factor).permute(0, 3, 1, 2)
-        out = F.conv2d(out, self.core_kernel, None, self.stride, self.padding, self.dilation, self.groups)
-        return HF.linear(out.permute(0, 2, 3, 1), self.last_factor, self.bias).permute(0, 3, 1, 2)
+        grad = torch.is_grad_enabled()
+        cache = None if grad else self.__dict__.setdefault("_plane_cache", {})
+        n = 1 if x.dtype == torch.bfloat16 else 3
+        p1 = None if grad else HF.planes_of(self.first_factor, n, cache=cache, tag="first")
+        out = HF.pointwise(x, self.first_factor, None, "tadmm_tucker_1x1", p1)
+        core = self.core_kernel if x.dtype == self.core_kernel.dtype else self.core_kernel.to(x.dtype)
+        out = F.conv2d(out, core, None, self.stride, self.padding, self.dilation, self.groups)
+        p3 = None if grad else HF.planes_of(self.last_factor, n, cache=cache, tag="last")
+        return HF.pointwise(out, self.last_factor, self.bias, "tadmm_tucker_1x1", p3)
 
 
 class TKConv2dR(_TKConvBase):

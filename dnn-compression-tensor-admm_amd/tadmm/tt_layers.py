@@ -153,8 +153,35 @@ class TTConv2dM(_TTConvBase):
             out = out + self.bias.view(1, -1, 1, 1)
         return out, flops, (h2, w2)
 
+    def _factors(self):
+        """Input cores contracted into (r, C), output cores into (O, r'): the two per-pixel maps around the core conv."""
+        w_in = _chain_recover(list(self.in_tt_cores)).reshape(self.in_tt_ranks[0], self.in_channels)
+        w_out = _chain_recover(list(self.out_tt_cores)).reshape(self.out_channels, self.out_tt_ranks[-1])
+        return w_in, w_out
+
     def forward(self, x):
-        return self._chains(x)[0]
+        """TTConv.py:130-153 as three launches: `tadmm_ttconv_chain_in` on the NCHW input in place (input cores
+        contracted), the k x k core convolution, `tadmm_ttconv_chain_out` + bias (output cores contracted)."""
+        if x.dtype not in (torch.float32, torch.bfloat16) or not self.in_tt_order or not self.out_tt_order:
+            return self._chains(x)[0]
+        params = list(self.in_tt_cores) + list(self.out_tt_cores)
+        grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        n = 1 if x.dtype == torch.bfloat16 else 3
+        if grad:
+            w_in, w_out = self._factors()
+            p_in = p_out = None
+        else:
+            cache = self.__dict__.setdefault("_chain_cache", {})
+            key = (n, x.device, tuple(p._version for p in params))
+            if cache.get("key") != key:
+                with torch.no_grad():
+                    w_in, w_out = self._factors()
+                cache.update(key=key, w=(w_in, w_out), planes=(HF.planes_of(w_in, n), HF.planes_of(w_out, n)))
+            (w_in, w_out), (p_in, p_out) = cache["w"], cache["planes"]
+        out = HF.pointwise(x, w_in, None, "tadmm_ttconv_chain_in", p_in)
+        core = self.core_kernel if x.dtype == self.core_kernel.dtype else self.core_kernel.to(x.dtype)
+        out = F.conv2d(out, core, None, self.stride, self.padding, self.dilation, self.groups)
+        return HF.pointwise(out, w_out, self.bias, "tadmm_ttconv_chain_out", p_out)
 
     def forward_flops(self, x):                                   # TTConv.py:155-195
         out, tt_flops, (h2, w2) = self._chains(x, True)
@@ -282,9 +309,44 @@ class TTLinearM(_TTLinearBase):
     def reset_parameters(self):
         self._init_cores()
 
+    def _factors(self):
+        """Input cores contracted into Win (r_q, in_features), output cores into Wout (out_features, r_q)."""
+        q = self.out_tt_order
+        w_out = _chain_recover(list(self.tt_cores[:q])).reshape(self.out_features, self.tt_ranks[q])
+        w_in = _chain_recover(list(self.tt_cores[q:])).reshape(self.tt_ranks[q], self.in_features)
+        return w_in, w_out
+
+    def _fused_ok(self, x):
+        q = self.out_tt_order
+        align = 8 if x.dtype == torch.bfloat16 else 4
+        return (x.dtype in (torch.float32, torch.bfloat16) and 0 < q < self.tt_order
+                and HF.fused_rank_ok(self.tt_ranks[q]) and self.in_features % align == 0)
+
     def forward(self, x):
+        """TTLinear.py:75-93.  One launch (`tadmm_ttlinear_fwd`) when the middle rank fits the fused kernel: the
+        input cores are contracted into Win, the output cores into Wout, and y = Wout (Win x) + bias with the
+        rank-r_q vector of a token held in LDS.  Otherwise the per-core GEMM chain below."""
+        if self._fused_ok(x):
+            grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.tt_cores)
+            if grad and x.dtype == torch.float32:
+                w_in, w_out = self._factors()
+                return HF.linear_chain(x, w_in, w_out, self.bias)
+            if not grad:
+                n = 1 if x.dtype == torch.bfloat16 else 3
+                cache = self.__dict__.setdefault("_chain_cache", {})
+                key = (n, x.device, tuple(p._version for p in self.tt_cores))
+                if cache.get("key") != key:
+                    with torch.no_grad():
+                        w_in, w_out = self._factors()
+                    cache.update(key=key, w=(w_in, w_out), planes=(HF.planes_of(w_in, n, pad_rows=64),
+                                                                   HF.planes_of(w_out, n, pad_cols=64)))
+                w_in, w_out = cache["w"]
+                return HF.linear_chain(x, w_in, w_out, self.bias, cache["planes"])
         if x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or self.tt_cores[0].requires_grad)):
             return self._forward_bf16(x)
+        return self._forward_chain(x)
+
+    def _forward_chain(self, x):
         out_shape = list(x.shape)
         out_shape[-1] = self.out_features
         q = self.out_tt_order

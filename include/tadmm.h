@@ -193,7 +193,7 @@ int tadmm_gemm_bf16_nt(tadmm_handle h, const void* A, const void* Bt, void* C, i
 /* ---- forward chains of the factorised layers (csrc/chain.hip) ---------------------------------------------------
  * One launch per chain on the bf16 matrix cores; the per-token intermediate stays in LDS.
  *   fused  : Y[t][:] = Wout (Win X[t][:]) + bias     TTLinearM (TTLinear.py:75-93); Win (R x Kin) / Wout (Nout x R)
- *            are the contracted input / output cores, R the middle TT rank (multiple of 32, <= 256; pad with zeros).
+ *            are the contracted input / output cores, R the middle TT rank (multiple of 64, <= 256; pad with zeros).
  *   single : Y[t][:] = Win X[t][:] + bias            N = R output features, any size.
  * dtype TADMM_CHAIN_F32: X, Y float32; weights as THREE bf16 planes (w = w1 + w2 + w3 exactly, plane p at
  *   W + p * plane_stride); six bf16 products per fp32 product, fp32 accumulate: fp32-GEMM accuracy.

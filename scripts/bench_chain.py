@@ -29,7 +29,7 @@ for name, kin, r, nout in (("qkv", 384, 256, 1152), ("proj", 384, 256, 384), ("f
         wd = (wout @ win).to(dtype)
         bias = torch.randn(nout, device="cuda")
         planes = 3 if dtype == torch.float32 else 1
-        wi, wo = ops.weight_planes(win, planes, 32), ops.weight_planes(wout, planes)
+        wi, wo = ops.weight_planes(win, planes, 64), ops.weight_planes(wout, planes)
         row = {"layer": name, "dtype": str(dtype).split(".")[1], "dense_ms": timeit(lambda: F.linear(x, wd, bias.to(dtype)))}
         for tile in (32, 64):
             row[f"fused_tm{tile}_ms"] = timeit(ops.chain_fused(x, wi, wo, bias, nout, tile_tokens=tile, prepare_only=True))

@@ -13,7 +13,7 @@ if len(sys.argv) > 1:
         win = torch.randn(r, kin, device="cuda") / kin ** 0.5
         wout = torch.randn(nout, r, device="cuda") / r ** 0.5
         planes = 3 if dtype == torch.float32 else 1
-        wi, wo = ops.weight_planes(win, planes, 32), ops.weight_planes(wout, planes)
+        wi, wo = ops.weight_planes(win, planes, 64), ops.weight_planes(wout, planes)
         for tile in (32, 64):
             go = ops.chain_fused(x, wi, wo, None, nout, tile_tokens=tile, prepare_only=True)
             for _ in range(5):

@@ -24,7 +24,7 @@ def _ref_fused(x, win, wout, bias):
     (12608, 384, 256, 1152, 0),      # DeiT-S qkv at the bench's token count
     (12608, 384, 256, 1152, 64),
     (197, 384, 96, 384, 0),          # ragged token tile, middle rank not a multiple of 64
-    (50, 72, 20, 40, 0),             # Kin, R, Nout all need padding (R padded to 32 by weight_planes)
+    (50, 72, 20, 40, 0),             # Kin, R, Nout all need padding (R padded to 64 by weight_planes)
     (1, 1536, 256, 384, 0),          # one token, long K (DeiT-S fc2)
 ])
 def test_fused_fp32_matches_fp64(T, kin, r, nout, tile):
@@ -34,8 +34,8 @@ def test_fused_fp32_matches_fp64(T, kin, r, nout, tile):
     win = (torch.randn(r, kin, generator=g) / kin ** 0.5).cuda()
     wout = (torch.randn(nout, r, generator=g) / r ** 0.5).cuda()
     bias = torch.randn(nout, generator=g).cuda()
-    wp_in = ops.weight_planes(win, 3, pad_rows=32)
-    wp_out = ops.weight_planes(wout, 3)
+    wp_in = ops.weight_planes(win, 3, pad_rows=64)
+    wp_out = ops.weight_planes(wout, 3, pad_cols=64)
     assert wp_out.shape[2] * 32 == wp_in.shape[1] * 16
     # the three planes reproduce the fp32 weight exactly
     assert torch.equal(ops.unpack_planes(wp_in).float().sum(0)[:r, :kin], win)
@@ -55,7 +55,7 @@ def test_fused_bf16(T, kin, r, nout, tile):
     win = (torch.randn(r, kin, generator=g) / kin ** 0.5).cuda()
     wout = (torch.randn(nout, r, generator=g) / r ** 0.5).cuda()
     bias = torch.randn(nout, generator=g).cuda()
-    wp_in, wp_out = ops.weight_planes(win, 1, pad_rows=32), ops.weight_planes(wout, 1)
+    wp_in, wp_out = ops.weight_planes(win, 1, pad_rows=64), ops.weight_planes(wout, 1, pad_cols=64)
     y = ops.chain_fused(x, wp_in, wp_out, bias, nout, tile_tokens=tile)
     assert y.dtype == torch.bfloat16
     ref = _ref_fused(x.float(), ops.unpack_planes(wp_in)[0, :r, :kin].float(), ops.unpack_planes(wp_out)[0, :nout, :r].float(), bias)
@@ -98,8 +98,8 @@ def test_single_product_rows_to_rows_and_errors():
     ref = x.double() @ w.double().t()
     assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
     # fused middle rank above the LDS-resident limit is refused, loudly
-    big = ops.weight_planes(torch.randn(288, 96, generator=g).cuda(), 3, pad_rows=32)
-    out = ops.weight_planes(torch.randn(64, 288, generator=g).cuda(), 3)
+    big = ops.weight_planes(torch.randn(320, 96, generator=g).cuda(), 3, pad_rows=64)
+    out = ops.weight_planes(torch.randn(64, 320, generator=g).cuda(), 3, pad_cols=64)
     with pytest.raises(TadmmError):
         ops.chain_fused(x, big, out, None, 64)
     with pytest.raises(TadmmError):
