@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-per-layer", action="store_true")
+    ap.add_argument("--no-forward", action="store_true", help="skip the factorised-layer forward block (hot path B)")
     ap.add_argument("--no-weak", action="store_true", help="N>1: skip the one-table-per-rank (weak scaling) pass")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: time every part of an N-way layer shard one after the other on this GPU")
@@ -360,6 +361,14 @@ def main():
         out["weak_scaling"] = {"value": world * args.steps / wel, "unit": "tables x iters/s", "tables": world,
                                "ms_per_step": 1e3 * wel / args.steps,
                                "note": "one table per rank (table r seeded r), no data-path collective, same K/W"}
+    # ---- hot path B: forward of the factorised layers against the dense layers they replace (tadmm/fwdbench.py)
+    if rank == 0 and world == 1 and not args.no_forward:
+        from tadmm import fwdbench
+        rows = fwdbench.run(dev)
+        head = next((r for r in rows if "qkv" in r["layer"] and r["dtype"] == "bf16" and "roofline" in r), None)
+        out["forward"] = {"note": "module call (inference, weights packed once) vs the dense torch layer of the same "
+                                  "shape and dtype; roofline = chain kernel alone, executed bf16 MFMA flops",
+                          "layers": rows, "roofline": None if head is None else head["roofline"]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.config)
     if rank == 0:

@@ -92,6 +92,10 @@ def _nplanes(x: torch.Tensor) -> int:
     raise TadmmError(-1, f"chain kernels take float32 or bfloat16 activations (got {x.dtype})")
 
 
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def fused_rank_ok(r: int) -> bool:
     """The fused chain keeps a token's middle-rank vector in LDS: ranks up to 256 (padded to a multiple of 64)."""
     return 0 < r <= 256
@@ -137,6 +141,13 @@ def pointwise(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, entry
     """Per-token / per-pixel linear map `x W^T + bias` with W (N, K): rows (..., K) or an image (B, K, H, W) in place
     (the 1x1 convolutions of TKConv.py:93-98 and the core chains of TTConv.py:131-151).  Differentiable.  `planes`:
     prebuilt `planes_of(w, ...)` (inference caches)."""
+    if not _needs_grad(x, w, bias):                   # inference: straight to the C ABI, no autograd node
+        if planes is None:
+            planes = planes_of(w, _nplanes(x))
+        if x.dim() == 4:
+            return ops.chain_single(x, planes, bias, w.shape[0], entry=entry, image_out=True)
+        lead = x.shape[:-1]
+        return ops.chain_single(x.reshape(-1, x.shape[-1]), planes, bias, w.shape[0], entry=entry).reshape(*lead, w.shape[0])
     if x.dim() == 4:
         return _ChainSingle.apply(x.contiguous(), w, bias, entry, planes)
     lead = x.shape[:-1]
@@ -184,4 +195,10 @@ def linear_chain(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor, bias:
     cores contracted into Win and the output cores into Wout).  Differentiable.  `planes`: prebuilt
     (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))."""
     lead = x.shape[:-1]
+    if not _needs_grad(x, w_in, w_out, bias):         # inference: straight to the C ABI, no autograd node
+        if planes is None:
+            n = _nplanes(x)
+            planes = (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))
+        return ops.chain_fused(x.reshape(-1, x.shape[-1]), planes[0], planes[1], bias, w_out.shape[0]).reshape(
+            *lead, w_out.shape[0])
     return _ChainFused.apply(x.reshape(-1, x.shape[-1]), w_in, w_out, bias, planes).reshape(*lead, w_out.shape[0])

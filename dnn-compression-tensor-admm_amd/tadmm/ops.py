@@ -341,64 +341,83 @@ def unpack_planes(wp: torch.Tensor) -> torch.Tensor:
     return wp.view(P, nt, ks, 4, 16, 8).permute(0, 1, 4, 2, 3, 5).reshape(P, nt * 16, ks * 32)
 
 
+_CHAIN_MEMO = {}
+
+
 def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin: int, n1: int, n_out: int,
                 image_out: bool, tile_tokens: int, prepare_only: bool = False):
     if not x.is_cuda:
         raise TadmmError(-1, "x must live on a HIP device; there is no CPU path")
-    if x.dtype == torch.float32:
-        dtype, planes = _cabi.CHAIN_F32, 3
-    elif x.dtype == torch.bfloat16:
-        dtype, planes = _cabi.CHAIN_BF16, 1
-    else:
-        raise TadmmError(-1, f"chain: unsupported dtype {x.dtype}")
-    if win.dtype != torch.bfloat16 or win.dim() != 5 or win.shape[0] != planes or not win.is_contiguous():
-        raise TadmmError(-1, f"chain: weights must be {planes} contiguous bf16 plane(s) (ops.weight_planes)")
-    d = _cabi.ChainDesc()
     if x.dim() == 4:                                   # (B, C, H, W) read in place
-        x = x.contiguous()
-        B, Cc, H, W = x.shape
-        assert Cc == kin
-        T, hw = B * H * W, H * W
-        d.x_hw, d.ldx = hw, 0
-    else:
-        assert x.dim() == 2 and x.shape[1] == kin
-        if x.stride(1) != 1 or (x.stride(0) * x.element_size()) % 16 or x.data_ptr() % 16:
+        if not x.is_contiguous():
             x = x.contiguous()
-        T, hw = x.shape[0], 0
-        d.x_hw, d.ldx = 0, x.stride(0)
-    feat = n_out if wout is not None else n1
-    if image_out:
-        assert hw > 0
-        y = torch.empty(x.shape[0], feat, x.shape[2], x.shape[3], dtype=x.dtype, device=x.device)
-        d.y_hw, d.ldy = hw, 0
-    else:
-        y = torch.empty(T, feat, dtype=x.dtype, device=x.device)
-        d.y_hw, d.ldy = 0, feat
-    if bias is not None:
+    elif x.stride(1) != 1 or (x.stride(0) * x.element_size()) % 16 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         bias = bias.detach().float().contiguous()
-    d.X, d.Y, d.Win = x.data_ptr(), y.data_ptr(), win.data_ptr()
-    d.Wout = None if wout is None else wout.data_ptr()
-    d.bias = None if bias is None else bias.data_ptr()
-    d.T, d.Kin, d.R, d.Nout = T, kin, n1, n_out if wout is not None else 0
-    if win.shape[2] != -(-kin // 32) or win.shape[1] * 16 < n1:
-        raise TadmmError(-1, "chain: weight planes do not match the operand shape")
-    d.win_plane = win[0].numel()
-    if wout is not None:
-        if wout.dtype != torch.bfloat16 or wout.dim() != 5 or wout.shape[0] != planes or not wout.is_contiguous():
+        bias_key = None                                 # a converted copy: nothing to memoise
+    else:
+        bias_key = 0 if bias is None else bias.data_ptr()
+    # geometry + weight identity -> validated descriptor; only the activation pointers change between calls
+    key = (entry, tuple(x.shape), x.stride(0), x.dtype, x.device, win.data_ptr(), 0 if wout is None else wout.data_ptr(),
+           bias_key, kin, n1, n_out, image_out, tile_tokens)
+    memo = _CHAIN_MEMO.get(key) if bias_key is not None else None
+    if memo is None:
+        if x.dtype == torch.float32:
+            dtype, planes = _cabi.CHAIN_F32, 3
+        elif x.dtype == torch.bfloat16:
+            dtype, planes = _cabi.CHAIN_BF16, 1
+        else:
+            raise TadmmError(-1, f"chain: unsupported dtype {x.dtype}")
+        if win.dtype != torch.bfloat16 or win.dim() != 5 or win.shape[0] != planes or not win.is_contiguous():
             raise TadmmError(-1, f"chain: weights must be {planes} contiguous bf16 plane(s) (ops.weight_planes)")
-        if wout.shape[2] * 32 != n1 or wout.shape[1] * 16 < n_out:
-            raise TadmmError(-1, "chain: output weight planes do not match the middle rank / output size")
-        d.wout_plane = wout[0].numel()
-    d.dtype, d.tile_tokens = dtype, tile_tokens
-    dev = x.device
-    h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
-    fn = getattr(h.lib, entry)
-    keep = (x, win, wout, bias, y)
+        d = _cabi.ChainDesc()
+        if x.dim() == 4:
+            B, Cc, H, W = x.shape
+            assert Cc == kin
+            T, hw = B * H * W, H * W
+            d.x_hw, d.ldx = hw, 0
+        else:
+            assert x.dim() == 2 and x.shape[1] == kin
+            T, hw = x.shape[0], 0
+            d.x_hw, d.ldx = 0, x.stride(0)
+        feat = n_out if wout is not None else n1
+        if image_out:
+            assert hw > 0
+            yshape = (x.shape[0], feat, x.shape[2], x.shape[3])
+            d.y_hw, d.ldy = hw, 0
+        else:
+            yshape = (T, feat)
+            d.y_hw, d.ldy = 0, feat
+        d.Win = win.data_ptr()
+        d.Wout = None if wout is None else wout.data_ptr()
+        d.bias = None if bias is None else bias.data_ptr()
+        d.T, d.Kin, d.R, d.Nout = T, kin, n1, n_out if wout is not None else 0
+        if win.shape[2] != -(-kin // 32) or win.shape[1] * 16 < n1:
+            raise TadmmError(-1, "chain: weight planes do not match the operand shape")
+        d.win_plane = win[0].numel()
+        if wout is not None:
+            if wout.dtype != torch.bfloat16 or wout.dim() != 5 or wout.shape[0] != planes or not wout.is_contiguous():
+                raise TadmmError(-1, f"chain: weights must be {planes} contiguous bf16 plane(s) (ops.weight_planes)")
+            if wout.shape[2] * 32 != n1 or wout.shape[1] * 16 < n_out:
+                raise TadmmError(-1, "chain: output weight planes do not match the middle rank / output size")
+            d.wout_plane = wout[0].numel()
+        d.dtype, d.tile_tokens = dtype, tile_tokens
+        dev = x.device
+        h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        memo = (d, getattr(h.lib, entry), h, yshape, T, (win, wout, bias))     # the tuple keeps the weights alive
+        if bias_key is not None:
+            if len(_CHAIN_MEMO) >= 1024:
+                _CHAIN_MEMO.clear()
+            _CHAIN_MEMO[key] = memo
+    d, fn, h, yshape, T, _ = memo
+    y = torch.empty(yshape, dtype=x.dtype, device=x.device)
 
     def launch():
+        d.X, d.Y = x.data_ptr(), y.data_ptr()
         if T > 0:
-            h.check(fn(h.ptr, C.byref(d), _stream(dev)))
-        return keep[-1]
+            h.check(fn(h.ptr, C.byref(d), _stream(x.device)))
+        return y
 
     if prepare_only:
         return launch

@@ -104,3 +104,72 @@ def test_single_product_rows_to_rows_and_errors():
         ops.chain_fused(x, big, out, None, 64)
     with pytest.raises(TadmmError):
         ops.chain_fused(x.cpu(), wp, wp, None, 64)
+
+
+# ------------------------------------------------------------------ the layers run on these kernels
+class _HP:
+    pass
+
+
+def _deit_qkv():
+    hp = _HP()
+    hp.tt_shapes = {"qkv.weight": [36, 32, 16, 24]}
+    hp.ranks = {"qkv.weight": [1, 25, 256, 18, 1]}
+    return hp
+
+
+def test_ttlinearm_uses_the_fused_entry_and_matches_the_per_core_chain(monkeypatch):
+    from tadmm import ops, tt_layers
+    torch.manual_seed(0)
+    lin = tt_layers.TTLinearM(384, 1152, bias=True, hp_dict=_deit_qkv(), name="qkv.weight").cuda()
+    with torch.no_grad():
+        lin.bias.normal_()
+    x = torch.randn(64, 197, 384, device="cuda")
+    calls = []
+    real = ops.chain_fused
+    monkeypatch.setattr(ops, "chain_fused", lambda *a, **k: (calls.append(k.get("entry", "tadmm_ttlinear_fwd")), real(*a, **k))[1])
+    with torch.no_grad():
+        y = lin(x)
+        ref = lin._forward_chain(x)                    # TTLinear.py:79-86 product by product on the fp32 GEMM
+    assert calls == ["tadmm_ttlinear_fwd"]
+    scale = ref.abs().max().item()
+    assert (y - ref).abs().max().item() < 5e-6 * scale
+    # bf16 inference: same kernel, one plane; bounded by bf16 rounding of x, H and y
+    with torch.no_grad():
+        yb = lin(x.bfloat16())
+    assert yb.dtype == torch.bfloat16 and calls[-1] == "tadmm_ttlinear_fwd"
+    assert (yb.float() - ref).abs().max().item() < 3e-2 * scale
+    # the packed factors follow in-place updates of the cores (version counters)
+    with torch.no_grad():
+        lin.tt_cores[1].mul_(2.0)
+        y2 = lin(x)
+        ref2 = lin._forward_chain(x)
+    assert (y2 - ref2).abs().max().item() < 5e-6 * ref2.abs().max().item()
+    assert (y2 - y).abs().max().item() > 1e-3 * scale
+
+
+def test_ttlinearm_fused_backward_matches_fp64_autograd():
+    from tadmm import tt_layers
+    torch.manual_seed(1)
+    hp = _HP()
+    hp.tt_shapes = {"w": [8, 6, 4, 12]}
+    hp.ranks = {"w": [1, 6, 40, 5, 1]}
+    lin = tt_layers.TTLinearM(48, 48, bias=True, hp_dict=hp, name="w").cuda()
+    x = torch.randn(70, 48, device="cuda", requires_grad=True)
+    y = lin(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    # fp64 reference: dense weight rebuilt from the cores (ttd.py:39-40), autograd through torch
+    cores = [c.detach().double().requires_grad_(True) for c in lin.tt_cores]
+    w = cores[0].reshape(-1, cores[0].shape[-1])
+    for c in cores[1:]:
+        w = w.reshape(-1, c.shape[0]) @ c.reshape(c.shape[0], -1)
+    xd = x.detach().double().requires_grad_(True)
+    bd = lin.bias.detach().double().requires_grad_(True)
+    yd = xd @ w.reshape(48, 48).t() + bd
+    yd.backward(gy.double())
+    assert (y.double() - yd).abs().max().item() < 1e-5 * yd.abs().max().item()
+    assert (x.grad.double() - xd.grad).abs().max().item() < 1e-5 * xd.grad.abs().max().item()
+    assert (lin.bias.grad.double() - bd.grad).abs().max().item() < 1e-5 * bd.grad.abs().max().item()
+    for c, cd in zip(lin.tt_cores, cores):
+        assert (c.grad.double() - cd.grad).abs().max().item() < 2e-5 * cd.grad.abs().max().item()
