@@ -305,6 +305,11 @@ def main():
         gemm_ms = ph["project_ms"] + ph["reconstruct_ms"]
         sweep_ms = ph["unfold_ms"] + ph["fold_update_ms"]
         out["phases_ms"] = ph
+        lanes = plan.lanes() if hasattr(plan, "lanes") else [0] * len(mine)
+        out["lanes"] = {"n": 1 + max(lanes), "layers_per_lane": [lanes.count(i) for i in range(1 + max(lanes))],
+                        "note": "two lanes = two sub-plans on two device streams (long eigen-solve chains on a high-"
+                                "priority stream, the rest beside them); phases_ms then sums both lanes and exceeds "
+                                "ms_per_step, and per-launch kernel times include the other lane's competition"}
         out["filter"] = fstats
         out["roofline_other"] = {
             "gram_f64_mfma": {"achieved_tflops": my_gram / (ph["gram_ms"] * 1e-3) / 1e12 if ph["gram_ms"] > 0 else 0.0,

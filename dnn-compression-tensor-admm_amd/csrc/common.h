@@ -32,8 +32,9 @@ struct SweepDesc {
 void launch_unfold(const SweepDesc* descs_dev, const BlockRef* map_dev, int nblocks, int use_u, hipStream_t s);
 void launch_fold_update(const SweepDesc* descs_dev, const BlockRef* map_dev, int nblocks, int update_u,
                         double* resid_partial_dev, hipStream_t s);
+// out_index (nullable): layer l's sum goes to resid_sq_dev[out_index[l]] (sub-plans of a two-lane plan)
 void launch_resid_reduce(const SweepDesc* descs_dev, int nlayers, const double* resid_partial_dev,
-                         double* resid_sq_dev, hipStream_t s);
+                         double* resid_sq_dev, hipStream_t s, const int32_t* out_index = nullptr);
 
 // ---------------------------------------------------------------- Gram (fp64 MFMA)
 struct GramDesc {
@@ -126,6 +127,16 @@ void launch_gemm_one(const GemmDesc& d, hipStream_t s);   // descriptor passed a
 // bf16 C[M][N] = A[M][K] * Bt[N][K]^T (+ f32 bias over N), fp32 accumulate (gemm_bf16.hip)
 void launch_gemm_bf16_nt(const void* A, const void* Bt, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
                          int64_t ldc, const float* bias_n, hipStream_t s);
+
+// ---------------------------------------------------------------- address spaces
+// A pointer fetched from a descriptor array has lost its address space as far as hipcc can tell, and the loads and
+// stores through it become flat_load / flat_store.  Those count on vmcnt AND lgkmcnt: every wait for an LDS read then
+// also drains the global loads in flight (and the other way round), which undoes any global -> LDS software pipeline.
+// `gp(p)` pins the global address space; a G<T>* dereferences to global_load / global_store.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+template <typename T> using G = T __attribute__((address_space(1)));
+template <typename T> __device__ __forceinline__ G<T>* gp(T* p) { return (G<T>*)p; }
+#endif
 
 // ---------------------------------------------------------------- forward chains of the factorised layers (chain.hip)
 struct ChainDesc {

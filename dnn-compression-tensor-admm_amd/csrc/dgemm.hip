@@ -204,9 +204,9 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   const DgemmDesc d = descs[br.prob];
   if (d.gate && *d.gate < d.gate_min) return;
   const int base = d.rot ? *d.rot : 0;
-  const double* __restrict__ A = dg_sel(d, d.selA, d.A, base);
-  const double* __restrict__ B = dg_sel(d, d.selB, d.B, base);
-  double* __restrict__ C = const_cast<double*>(dg_sel(d, d.selC, d.C, base));
+  const G<const double>* __restrict__ A = gp(dg_sel(d, d.selA, d.A, base));
+  const G<const double>* __restrict__ B = gp(dg_sel(d, d.selB, d.B, base));
+  G<double>* __restrict__ C = gp(const_cast<double*>(dg_sel(d, d.selC, d.C, base)));
   const int tiles_n = (d.N + TN - 1) / TN;
   const int tm = br.local / tiles_n, tn = br.local - tm * tiles_n;
   const int m0 = tm * kDT, n0 = tn * TN;
@@ -226,16 +226,16 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   // Rows beyond an edge are clamped, not predicated: a row of A (B) only feeds its own output row (column), which
   // the epilogue never stores, and unconditional loads let the compiler count them (a branch per load makes it wait
   // for vmcnt(0) at every LDS store, which serialises the whole prefetch).
-  const double* pa[AP]; const double* pb[BP];
+  const G<const double>* pa[AP]; const G<const double>* pb[BP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) pa[i] = A + (int64_t)min(m0 + srow + RS * i, d.M - 1) * lda + 2 * sc2;
 #pragma unroll
   for (int i = 0; i < BP; ++i) pb[i] = B + (int64_t)min(n0 + srow + RS * i, d.N - 1) * ldb + 2 * sc2;
   auto gload = [&](Regs& R, int k0) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) R.a[i] = *reinterpret_cast<const double2_t*>(pa[i] + k0);
+    for (int i = 0; i < AP; ++i) R.a[i] = *reinterpret_cast<const G<const double2_t>*>(pa[i] + k0);
 #pragma unroll
-    for (int i = 0; i < BP; ++i) R.b[i] = *reinterpret_cast<const double2_t*>(pb[i] + k0);
+    for (int i = 0; i < BP; ++i) R.b[i] = *reinterpret_cast<const G<const double2_t>*>(pb[i] + k0);
   };
   auto sstore = [&](const Regs& R, int stage) {
     double (*As)[kDLd] = reinterpret_cast<double (*)[kDLd]>(smem + stage * kBuf);
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   const int mode = d.mode;
   double s0 = 1.0, s1 = 0.0, s2 = 0.0;
   if (mode == 1) { s0 = d.coef[0]; s1 = d.coef[1]; s2 = d.coef[2]; }
-  const double* __restrict__ P = (mode >= 1) ? dg_sel(d, d.selP, d.P, base) : nullptr;
-  const double* __restrict__ Q = (mode == 1 && s2 != 0.0) ? dg_sel(d, d.selQ, d.Q, base) : nullptr;
+  const G<const double>* __restrict__ P = gp((mode >= 1) ? dg_sel(d, d.selP, d.P, base) : nullptr);
+  const G<const double>* __restrict__ Q = gp((mode == 1 && s2 != 0.0) ? dg_sel(d, d.selQ, d.Q, base) : nullptr);
   const int64_t ldc = d.ldc;
   const int row = tid >> 2, c0 = (tid & 3) * CPT;
   const bool rok = m0 + row < d.M;
@@ -343,18 +343,18 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
       const int64_t gi = (int64_t)(m0 + row) * ldc + n0 + col;
       const double v0 = Ct[row][col], v1 = Ct[row][col + 1];
       if (mode == 0) {
-        *reinterpret_cast<double2_t*>(C + gi) = double2_t{v0, v1};
+        *reinterpret_cast<G<double2_t>*>(C + gi) = double2_t{v0, v1};
       } else {
-        const double2_t p = *reinterpret_cast<const double2_t*>(P + gi);
+        const double2_t p = *reinterpret_cast<const G<const double2_t>*>(P + gi);
         if (mode == 1) {
           double o0 = s0 * v0 + s1 * p.x, o1 = s0 * v1 + s1 * p.y;
           if (Q) {
-            const double2_t qq = *reinterpret_cast<const double2_t*>(Q + gi);
+            const double2_t qq = *reinterpret_cast<const G<const double2_t>*>(Q + gi);
             o0 += s2 * qq.x; o1 += s2 * qq.y;
           }
-          *reinterpret_cast<double2_t*>(C + gi) = double2_t{o0, o1};
+          *reinterpret_cast<G<double2_t>*>(C + gi) = double2_t{o0, o1};
         } else if (mode == 2) {
-          *reinterpret_cast<double2_t*>(C + gi) = double2_t{v0, v1};
+          *reinterpret_cast<G<double2_t>*>(C + gi) = double2_t{v0, v1};
           part += v0 * p.x + v1 * p.y;
         } else {
           const double e0 = v0 - th * p.x, e1 = v1 - th * p.y;

@@ -17,6 +17,9 @@
 #include "filter_host.h"
 
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 using namespace tadmm;
 
@@ -187,6 +190,31 @@ struct tadmm_plan_s {
   // filtered eigen-solver statistics of the last run
   int filt_problems = 0, filt_fallbacks = 0, filt_stages = 0;
   FilterTiming ftm;
+  const int32_t* resid_index = nullptr;   // device map local layer -> slot of the caller's residual array (lanes)
+  struct Lanes* lanes = nullptr;          // set on a parent plan that runs its layers as two concurrent lanes
+};
+
+// ------------------------------------------------------------------------------------------------
+// Lanes.  One eigen-solve is a chain of dependent launches, and the grouped launches of a plan put the short chains
+// of most layers behind the few long ones (ResNet-50: the 3x3 kernels of layer3/layer4 need ~3/4 of the launches).
+// A plan whose table has both kinds is therefore run as TWO sub-plans on two streams of the device: lane 0 holds the
+// long chains and runs on a high-priority stream at the pace it would have alone, lane 1 (everything else) fills the
+// CUs those launches leave idle.  Each sub-plan polls its own convergence words, so lane 1 is driven by a worker thread
+// that lives as long as the plan.  Measured on MI355X, ResNet-50 table: 10.2 ms as one plan, 8.6 ms as two lanes.
+// ------------------------------------------------------------------------------------------------
+struct Lanes {
+  tadmm_plan_s* sub[2] = {nullptr, nullptr};
+  std::vector<int> lane_of, local_of;
+  hipStream_t st[2] = {nullptr, nullptr};
+  hipEvent_t ev_begin = nullptr, ev_end[2] = {nullptr, nullptr};
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  int job = 0;                 // 0 idle, 1 run posted, 2 quit
+  bool done = true;
+  int a_update_u = 0, a_use_u = 0;
+  double* a_resid = nullptr;
+  int rc = 0;
 };
 
 namespace {
@@ -634,7 +662,7 @@ int tadmm_tt_clamp_ranks(tadmm_layer_desc* desc) {
   return clamp_ranks(desc);
 }
 
-int tadmm_plan_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, size_t* bytes) {
+static int single_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, size_t* bytes) {
   if (!h || !descs || !bytes || n_layers <= 0) return TADMM_ERR_INVALID;
   tadmm_plan_s P;
   P.h = h;
@@ -652,9 +680,9 @@ int tadmm_plan_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_d
   return TADMM_OK;
 }
 
-int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
-                      float* const* U, float* const* Z, float* const* cores, void* workspace, size_t workspace_bytes,
-                      tadmm_plan* out) {
+static int single_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
+                         float* const* U, float* const* Z, float* const* cores, void* workspace, size_t workspace_bytes,
+                         tadmm_plan* out) {
   DeviceGuard device_guard(h);
   if (!h || !descs || !W || !U || !Z || !workspace || !out || n_layers <= 0) return TADMM_ERR_INVALID;
   tadmm_plan_s* P = new tadmm_plan_s();
@@ -701,9 +729,216 @@ int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* desc
   return TADMM_OK;
 }
 
+static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_);
+
+// ---- lanes: split rule, creation, the worker of lane 1 ----
+// modelled latency (us) of one eigen-problem alone on the device; mirrors tadmm/sched.py problem_latency_us
+static double step_latency_us(int N, int r) {
+  const int npad = (int)align_up(N, 32);
+  if (npad <= 64) return 100.0;
+  const int rp = filter_block_size(N, r);
+  if (rp) return 7.0 * (8 * 35.0 + 170.0) + (rp / 16 - 1) * 7.0 * (9.0 + 0.02 * (double)align_up(rp, 128));
+  return (npad / 16 - 1) * 11.0 * (9.0 + 0.02 * (double)align_up(N, 128));
+}
+
+// lane 0 = layers whose chain of eigen-solves is at least `thr` of the longest; lane 1 = the rest.  One lane (return
+// false) when either side would be (nearly) empty, when asked to (TADMM_LANES=1) or for small tables.
+static bool lane_split(tadmm_handle h, int n, const tadmm_layer_desc* descs, std::vector<int>& lane_of) {
+  lane_of.assign(n, 0);
+  if (const char* e = getenv("TADMM_LANES")) if (atoi(e) == 1) return false;
+  if (n < 4) return false;
+  double thr = 0.6;
+  if (const char* e = getenv("TADMM_LANE_THRESHOLD")) thr = atof(e);
+  std::vector<double> lat(n, 0.0);
+  double lmax = 0.0;
+  for (int l = 0; l < n; ++l) {
+    LayerGeom g;
+    if (build_geom(h, descs[l], g)) return false;
+    for (const StepGeom& st : g.steps) if (!st.skip) lat[l] += step_latency_us(st.N, st.r);
+    lmax = std::max(lmax, lat[l]);
+  }
+  int n0 = 0;
+  double t1 = 0.0;
+  for (int l = 0; l < n; ++l) {
+    lane_of[l] = lat[l] >= thr * lmax ? 0 : 1;
+    if (lane_of[l] == 0) ++n0; else t1 += lat[l];
+  }
+  if (n0 == 0 || n - n0 < 2 || t1 < 0.2 * lmax) { lane_of.assign(n, 0); return false; }
+  return true;
+}
+
+static void lane_worker(tadmm_plan_s* parent) {
+  Lanes* L = parent->lanes;
+  (void)hipSetDevice(parent->h->device);
+  for (;;) {
+    std::unique_lock<std::mutex> lk(L->mu);
+    L->cv.wait(lk, [&] { return L->job != 0; });
+    if (L->job == 2) return;
+    const int uu = L->a_update_u, us = L->a_use_u;
+    double* resid = L->a_resid;
+    lk.unlock();
+    const int rc = single_run(L->sub[1], uu, us, resid, L->st[1]);
+    lk.lock();
+    L->rc = rc;
+    L->job = 0;
+    L->done = true;
+    lk.unlock();
+    L->cv.notify_all();
+  }
+}
+
+static void lanes_destroy(tadmm_plan_s* p);
+
+int tadmm_plan_workspace_bytes(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, size_t* bytes) {
+  if (!h || !descs || !bytes || n_layers <= 0) return TADMM_ERR_INVALID;
+  std::vector<int> lane_of;
+  if (!lane_split(h, n_layers, descs, lane_of)) return single_workspace_bytes(h, n_layers, descs, bytes);
+  size_t total = 0;
+  for (int lane = 0; lane < 2; ++lane) {
+    std::vector<tadmm_layer_desc> sub;
+    for (int l = 0; l < n_layers; ++l) if (lane_of[l] == lane) sub.push_back(descs[l]);
+    size_t b = 0;
+    const int rc = single_workspace_bytes(h, (int)sub.size(), sub.data(), &b);
+    if (rc) return rc;
+    total += align_up(b, 4096);
+  }
+  *bytes = total + align_up((size_t)n_layers * 4, 4096);
+  return TADMM_OK;
+}
+
+int tadmm_plan_create(tadmm_handle h, int n_layers, const tadmm_layer_desc* descs, const float* const* W,
+                      float* const* U, float* const* Z, float* const* cores, void* workspace, size_t workspace_bytes,
+                      tadmm_plan* out) {
+  DeviceGuard device_guard(h);
+  if (!h || !descs || !W || !U || !Z || !workspace || !out || n_layers <= 0) return TADMM_ERR_INVALID;
+  std::vector<int> lane_of;
+  if (!lane_split(h, n_layers, descs, lane_of))
+    return single_create(h, n_layers, descs, W, U, Z, cores, workspace, workspace_bytes, out);
+  tadmm_plan_s* P = new tadmm_plan_s();
+  P->h = h;
+  P->n = n_layers;
+  P->layers.resize(n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    const int rc = build_geom(h, descs[l], P->layers[l]);
+    if (rc) { delete P; return rc; }
+  }
+  Lanes* L = new Lanes();
+  P->lanes = L;
+  L->lane_of = lane_of;
+  L->local_of.assign(n_layers, 0);
+  char* ws = (char*)workspace;
+  size_t off = 0;
+  std::vector<int32_t> index_host;                                   // [lane 0 layers | lane 1 layers] -> global slot
+  size_t index_off[2] = {0, 0};
+  for (int lane = 0; lane < 2; ++lane) {
+    index_off[lane] = index_host.size();
+    for (int l = 0; l < n_layers; ++l) if (lane_of[l] == lane) { L->local_of[l] = (int)(index_host.size() - index_off[lane]); index_host.push_back(l); }
+  }
+  int rc = TADMM_OK;
+  size_t sub_bytes[2] = {0, 0};
+  for (int lane = 0; lane < 2 && rc == TADMM_OK; ++lane) {
+    std::vector<tadmm_layer_desc> sd;
+    std::vector<const float*> sw;
+    std::vector<float*> su, sz, sc;
+    for (int l = 0; l < n_layers; ++l) if (lane_of[l] == lane) {
+      sd.push_back(descs[l]); sw.push_back(W[l]); su.push_back(U[l]); sz.push_back(Z[l]); sc.push_back(cores ? cores[l] : nullptr);
+    }
+    rc = single_workspace_bytes(h, (int)sd.size(), sd.data(), &sub_bytes[lane]);
+    if (rc) break;
+    const size_t need = align_up(sub_bytes[lane], 4096);
+    if (off + need > workspace_bytes) { rc = TADMM_ERR_WORKSPACE; h->err = "workspace too small for the two lanes"; break; }
+    rc = single_create(h, (int)sd.size(), sd.data(), sw.data(), su.data(), sz.data(), cores ? sc.data() : nullptr, ws + off,
+                       need, &L->sub[lane]);
+    off += need;
+  }
+  if (rc == TADMM_OK && off + (size_t)n_layers * 4 > workspace_bytes) { rc = TADMM_ERR_WORKSPACE; h->err = "workspace too small for the lane index"; }
+  if (rc == TADMM_OK) {
+    if (hipMemcpy(ws + off, index_host.data(), index_host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = TADMM_ERR_HIP;
+    for (int lane = 0; lane < 2; ++lane) L->sub[lane]->resid_index = (const int32_t*)(ws + off) + index_off[lane];
+  }
+  if (rc == TADMM_OK) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                 // hi is the numerically smaller, more urgent one
+    hipError_t e = hipStreamCreateWithPriority(&L->st[0], hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&L->st[1], hipStreamNonBlocking, lo);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&L->ev_begin, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&L->ev_end[i], hipEventDisableTiming);
+    if (e != hipSuccess) { rc = TADMM_ERR_HIP; h->err = std::string("lane streams: ") + hipGetErrorString(e); }
+  }
+  if (rc != TADMM_OK) { lanes_destroy(P); delete P; return rc; }
+  L->worker = std::thread(lane_worker, P);
+  *out = P;
+  return TADMM_OK;
+}
+
+int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_) {
+  if (!p) return TADMM_ERR_INVALID;
+  if (!p->lanes) return single_run(p, update_u, use_u, resid_sq_dev, stream_);
+  DeviceGuard device_guard(p->h);
+  Lanes* L = p->lanes;
+  hipStream_t s = (hipStream_t)stream_;
+  HIP_OK(p->h, hipEventRecord(L->ev_begin, s));                      // both lanes start behind the caller's stream
+  for (int i = 0; i < 2; ++i) HIP_OK(p->h, hipStreamWaitEvent(L->st[i], L->ev_begin, 0));
+  {
+    std::lock_guard<std::mutex> lk(L->mu);
+    L->a_update_u = update_u; L->a_use_u = use_u; L->a_resid = resid_sq_dev;
+    L->done = false;
+    L->job = 1;
+  }
+  L->cv.notify_all();
+  const int rc0 = single_run(L->sub[0], update_u, use_u, resid_sq_dev, L->st[0]);
+  int rc1;
+  {
+    std::unique_lock<std::mutex> lk(L->mu);
+    L->cv.wait(lk, [&] { return L->done; });
+    rc1 = L->rc;
+  }
+  for (int i = 0; i < 2; ++i) {                                      // ... and the caller's stream continues behind both
+    HIP_OK(p->h, hipEventRecord(L->ev_end[i], L->st[i]));
+    HIP_OK(p->h, hipStreamWaitEvent(s, L->ev_end[i], 0));
+  }
+  for (int i = 0; i < 8; ++i) p->last_ms[i] = L->sub[0]->last_ms[i] + L->sub[1]->last_ms[i];
+  p->last_sweeps = L->sub[0]->last_sweeps + L->sub[1]->last_sweeps;
+  return rc0 != TADMM_OK ? rc0 : rc1;
+}
+
+static void lanes_destroy(tadmm_plan_s* p) {
+  Lanes* L = p->lanes;
+  if (!L) return;
+  if (L->worker.joinable()) {
+    { std::lock_guard<std::mutex> lk(L->mu); L->job = 2; }
+    L->cv.notify_all();
+    L->worker.join();
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (L->sub[i]) {
+      if (L->sub[i]->ev_made) for (auto& e : L->sub[i]->ev) (void)hipEventDestroy(e);
+      L->sub[i]->poll.destroy();
+      delete L->sub[i];
+    }
+    if (L->st[i]) { (void)hipStreamSynchronize(L->st[i]); (void)hipStreamDestroy(L->st[i]); }
+    if (L->ev_end[i]) (void)hipEventDestroy(L->ev_end[i]);
+  }
+  if (L->ev_begin) (void)hipEventDestroy(L->ev_begin);
+  delete L;
+  p->lanes = nullptr;
+}
+
+int tadmm_plan_lanes(tadmm_plan p, int32_t* lane_of_out) {
+  if (!p) return TADMM_ERR_INVALID;
+  if (!p->lanes) { if (lane_of_out) for (int l = 0; l < p->n; ++l) lane_of_out[l] = 0; return 1; }
+  if (lane_of_out) for (int l = 0; l < p->n; ++l) lane_of_out[l] = p->lanes->lane_of[l];
+  return 2;
+}
+
 int tadmm_plan_enable_timing(tadmm_plan p, int on) {
   DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_ERR_INVALID;
+  if (p->lanes) {
+    for (int i = 0; i < 2; ++i) { const int rc = tadmm_plan_enable_timing(p->lanes->sub[i], on); if (rc) return rc; }
+    p->timing = on != 0;
+    return TADMM_OK;
+  }
   if (on && !p->ev_made) {
     for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) return TADMM_ERR_HIP;
     p->ev_made = true;
@@ -719,7 +954,7 @@ int tadmm_plan_last_timing(tadmm_plan p, double out_ms[8]) {
   return TADMM_OK;
 }
 
-int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_) {
+static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, void* stream_) {
   DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_ERR_INVALID;
   tadmm_handle h = p->h;
@@ -842,7 +1077,8 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
   double* partial = (double*)D(p->resid_partial_off);
   launch_fold_update((const SweepDesc*)D(p->sweep_desc_off), (const BlockRef*)D(p->fold.map_off), p->fold.nblocks,
                      update_u, partial, s);
-  if (resid_sq_dev) launch_resid_reduce((const SweepDesc*)D(p->sweep_desc_off), p->n, partial, resid_sq_dev, s);
+  if (resid_sq_dev)
+    launch_resid_reduce((const SweepDesc*)D(p->sweep_desc_off), p->n, partial, resid_sq_dev, s, p->resid_index);
   toc(0, 5);
   HIP_OK(h, hipGetLastError());
   for (int i = 0; i < 8; ++i) p->last_ms[i] = acc_ms[i];
@@ -854,6 +1090,8 @@ int tadmm_plan_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_dev, 
 int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_host, void* stream_) {
   DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p || !out_host || layer < 0 || layer >= p->n) return TADMM_ERR_INVALID;
+  if (p->lanes)
+    return tadmm_plan_singular_values(p->lanes->sub[p->lanes->lane_of[layer]], p->lanes->local_of[layer], step, out_host, stream_);
   const LayerGeom& g = p->layers[layer];
   if (step < 0 || step >= (int)g.steps.size()) return TADMM_ERR_INVALID;
   const size_t off = p->sigma_off[layer][step];
@@ -866,12 +1104,27 @@ int tadmm_plan_singular_values(tadmm_plan p, int layer, int step, double* out_ho
 
 int tadmm_plan_filter_timing(tadmm_plan p, double out[4]) {
   if (!p || !out) return TADMM_ERR_INVALID;
+  if (p->lanes) {
+    double a[4], b[4];
+    tadmm_plan_filter_timing(p->lanes->sub[0], a);
+    tadmm_plan_filter_timing(p->lanes->sub[1], b);
+    for (int i = 0; i < 4; ++i) out[i] = a[i] + b[i];
+    return TADMM_OK;
+  }
   out[0] = p->ftm.gemm_ms; out[1] = p->ftm.gemm_launches; out[2] = p->ftm.gemm_flops; out[3] = 0.0;
   return TADMM_OK;
 }
 
 int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]) {
   if (!p || !out) return TADMM_ERR_INVALID;
+  if (p->lanes) {
+    int32_t a[4], b[4];
+    tadmm_plan_filter_stats(p->lanes->sub[0], a);
+    tadmm_plan_filter_stats(p->lanes->sub[1], b);
+    for (int i = 0; i < 3; ++i) out[i] = a[i] + b[i];
+    out[3] = std::max(a[3], b[3]);
+    return TADMM_OK;
+  }
   int eligible = 0;
   for (const StepPlan& sp : p->steps) eligible += sp.fg.nf;
   out[0] = eligible; out[1] = p->filt_problems; out[2] = p->filt_fallbacks; out[3] = p->filt_stages;
@@ -881,6 +1134,7 @@ int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]) {
 int tadmm_plan_destroy(tadmm_plan p) {
   DeviceGuard device_guard(p ? p->h : nullptr);
   if (!p) return TADMM_OK;
+  lanes_destroy(p);
   if (p->ev_made) for (auto& e : p->ev) (void)hipEventDestroy(e);
   p->poll.destroy();
   delete p;
@@ -889,6 +1143,7 @@ int tadmm_plan_destroy(tadmm_plan p) {
 
 int tadmm_plan_set_jacobi(tadmm_plan p, double tol, int inner_sweeps, int max_sweeps) {
   if (!p) return TADMM_ERR_INVALID;
+  if (p->lanes) for (int i = 0; i < 2; ++i) tadmm_plan_set_jacobi(p->lanes->sub[i], tol, inner_sweeps, max_sweeps);
   if (tol > 0) p->tol = tol;
   if (inner_sweeps > 0) p->inner_sweeps = inner_sweeps;
   if (max_sweeps > 0) p->max_global_sweeps = max_sweeps;

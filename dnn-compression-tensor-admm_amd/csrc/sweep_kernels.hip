@@ -153,12 +153,13 @@ __global__ __launch_bounds__(kSweepThreads) void fold_update_kernel(const SweepD
 // one wave per layer, fixed summation order -> run-to-run deterministic
 __global__ __launch_bounds__(64) void resid_reduce_kernel(const SweepDesc* __restrict__ descs,
                                                           const double* __restrict__ resid_partial,
-                                                          double* __restrict__ resid_sq) {
+                                                          double* __restrict__ resid_sq,
+                                                          const int32_t* __restrict__ out_index) {
   const SweepDesc d = descs[blockIdx.x];
   double acc = 0.0;
   for (int i = threadIdx.x; i < d.nblk; i += 64) acc += resid_partial[d.blk_begin + i];
   acc = wave_sum(acc);
-  if (threadIdx.x == 0) resid_sq[blockIdx.x] = acc;
+  if (threadIdx.x == 0) resid_sq[out_index ? out_index[blockIdx.x] : blockIdx.x] = acc;
 }
 
 void launch_unfold(const SweepDesc* descs_dev, const BlockRef* map_dev, int nblocks, int use_u, hipStream_t s) {
@@ -175,9 +176,10 @@ void launch_fold_update(const SweepDesc* descs_dev, const BlockRef* map_dev, int
 }
 
 void launch_resid_reduce(const SweepDesc* descs_dev, int nlayers, const double* resid_partial_dev,
-                         double* resid_sq_dev, hipStream_t s) {
+                         double* resid_sq_dev, hipStream_t s, const int32_t* out_index) {
   if (nlayers <= 0) return;
-  hipLaunchKernelGGL(resid_reduce_kernel, dim3(nlayers), dim3(64), 0, s, descs_dev, resid_partial_dev, resid_sq_dev);
+  hipLaunchKernelGGL(resid_reduce_kernel, dim3(nlayers), dim3(64), 0, s, descs_dev, resid_partial_dev, resid_sq_dev,
+                     out_index);
 }
 
 // ---------------------------------------------------------------- penalty (admm.py:80-85)

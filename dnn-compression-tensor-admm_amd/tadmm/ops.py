@@ -111,6 +111,13 @@ class ProjectionPlan:
         keys = ["unfold_ms", "gram_ms", "eig_ms", "project_ms", "reconstruct_ms", "fold_update_ms", "jacobi_sweeps"]
         return {k: float(out[i]) for i, k in enumerate(keys)}
 
+    def lanes(self) -> List[int]:
+        """Lane of every layer: all 0 for a one-lane plan; long chains 0 / the rest 1 when the plan runs as two
+        concurrent sub-plans (include/tadmm.h, tadmm_plan_lanes)."""
+        out = (C.c_int32 * self.n)()
+        self.h.lib.tadmm_plan_lanes(self._plan, out)
+        return [int(x) for x in out]
+
     def filter_stats(self) -> dict:
         """Filtered eigen-solver counters: eligible problems of the plan; of the last run: solves, fallbacks, stages."""
         out = (C.c_int32 * 4)()

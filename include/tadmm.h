@@ -129,6 +129,13 @@ int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]);
 int tadmm_plan_filter_timing(tadmm_plan p, double out[4]);
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
+/* Lanes.  A plan whose table mixes long chains of eigen-solves (e.g. the 3x3 kernels of ResNet layer3/layer4) with
+ * short ones runs as two sub-plans on two device streams -- the long chains on a high-priority stream, the rest
+ * filling the CUs they leave idle; the caller's stream is joined in front and behind, the second lane is driven by a
+ * worker thread owned by the plan.  Returns the number of lanes (1 or 2) and, when lane_of_out is not NULL, each
+ * layer's lane.  TADMM_LANES=1 in the environment keeps every plan in one lane; TADMM_LANE_THRESHOLD (default 0.6)
+ * is the fraction of the longest modelled chain from which a layer counts as long. */
+int tadmm_plan_lanes(tadmm_plan p, int32_t* lane_of_out);
 int tadmm_plan_destroy(tadmm_plan p);
 
 /* ---- Tucker-2 projection plan (admm.py:113-127: tensorly partial_tucker + tucker_to_tensor) ---- */

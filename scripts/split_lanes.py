@@ -30,3 +30,28 @@ def both():
     ta, tb = threading.Thread(target=ra), threading.Thread(target=rb)
     ta.start(); tb.start(); ta.join(); tb.join()
 print("A || B on two streams / threads %.2f ms" % timeit(both))
+# --- with stream priorities: the long chains first
+lo, hi = -1, 0
+try:
+    import ctypes
+    rng = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None
+    print("priority range", rng)
+except Exception as ex:
+    print("no priority_range", ex)
+for pa_prio, pb_prio in ((-1, 0), (0, -1)):
+    sa, sb = torch.cuda.Stream(priority=pa_prio), torch.cuda.Stream(priority=pb_prio)
+    print("A prio %d, B prio %d: %.2f ms" % (pa_prio, pb_prio, timeit(both)))
+pa.close(); pb.close()
+# --- other splits
+def split(pred, label):
+    global pa, pb, sa, sb
+    A2 = [e for e, n in zip(entries, names) if pred(n)]
+    B2 = [e for e, n in zip(entries, names) if not pred(n)]
+    pa, pb = ops.ProjectionPlan(A2), ops.ProjectionPlan(B2)
+    ta_, tb_ = timeit(lambda: pa.run(True)), timeit(lambda: pb.run(True))
+    for pr in ((0, 0), (-1, 0)):
+        sa, sb = torch.cuda.Stream(priority=pr[0]), torch.cuda.Stream(priority=pr[1])
+        print("%s: A %d layers %.2f ms, B %d layers %.2f ms, both (prio %s) %.2f ms" % (label, len(A2), ta_, len(B2), tb_, pr, timeit(both)))
+    pa.close(); pb.close()
+split(lambda n: n.startswith("layer4.") and ".conv2." in n, "layer4.conv2")
+split(lambda n: (n.startswith("layer4.") or n.startswith("layer3.")) and ".conv2." in n, "layer3+4.conv2")
