@@ -636,6 +636,8 @@ int tadmm_abi_sizes(int* layer_desc_bytes, int* gemm_desc_bytes) {
   return TADMM_OK;
 }
 
+int tadmm_chain_desc_bytes(void) { return (int)sizeof(tadmm_chain_desc); }
+
 int tadmm_create(int device, tadmm_handle* out) {
   if (!out) return TADMM_ERR_INVALID;
   int count = 0;

@@ -108,6 +108,7 @@ ABI = {
     "tadmm_gemm": (C.c_int, [C.c_void_p, C.POINTER(GemmDesc), C.c_void_p]),
     "tadmm_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tadmm_chain_desc_bytes": (C.c_int, []),
     "tadmm_ttlinear_fwd": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
     "tadmm_ttlinear_bwd": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
     "tadmm_ttconv_chain_in": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
@@ -171,6 +172,9 @@ def load():
         if (a.value, b.value) != (C.sizeof(LayerDesc), C.sizeof(GemmDesc)):
             raise TadmmLibraryError(f"{path}: struct layout mismatch (library {a.value}/{b.value} bytes, "
                                     f"binding {C.sizeof(LayerDesc)}/{C.sizeof(GemmDesc)})")
+        if lib.tadmm_chain_desc_bytes() != C.sizeof(ChainDesc):
+            raise TadmmLibraryError(f"{path}: tadmm_chain_desc layout mismatch (library {lib.tadmm_chain_desc_bytes()} "
+                                    f"bytes, binding {C.sizeof(ChainDesc)})")
         _lib = lib
         return lib
 

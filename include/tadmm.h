@@ -222,6 +222,8 @@ typedef struct {
   int32_t x_hw, y_hw;
   int32_t dtype, tile_tokens;
 } tadmm_chain_desc;
+/* sizeof(tadmm_chain_desc) as the library was built (bindings check their struct layout against it) */
+int tadmm_chain_desc_bytes(void);
 /* TTLinearM forward (TTLinear.py:75-93), fused. */
 int tadmm_ttlinear_fwd(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
 /* TTLinearM data gradient dX = (dY Wout) Win: the same fused kernel with X = dY, Win = Wout^T planes (R x Nout),

@@ -4,8 +4,16 @@ import csv, glob, os, re, sys, collections, json
 
 def norm(n):
     """kernel name without return type, namespace, template arguments and parameter list"""
-    n = n.split("(")[0].replace("tadmm::", "").replace("void ", "")
-    return re.sub(r"<.*>", "", n).strip()
+    n = n.replace("(anonymous namespace)::", "").replace("tadmm::", "").replace("void ", "")
+    m = re.match(r"\s*([A-Za-z_][\w:]*)\s*(<.*>)?\s*\(", n + "(")
+    if not m:
+        return n.split("(")[0].strip()
+    name, targs = m.group(1), m.group(2) or ""
+    if name == "tt_chain_kernel" and targs:                 # keep the mode: planes, token tile, fused / single
+        a = [t.strip() for t in targs[1:-1].split(",")]
+        if len(a) >= 8:
+            return "tt_chain_kernel<P=%s,TM=%s,%s>" % (a[0], a[1], "fused" if a[7] == "true" else "single")
+    return name
 
 
 out = sys.argv[1]
