@@ -167,6 +167,7 @@ struct DgemmDesc {
   const double* theta;                                    // mode 3: per-row shift
   double* rowpart;                                        // modes 2, 3: [tiles_n][M] fixed-order row partials
   const int32_t* gate; int32_t gate_min;                  // no-op unless *gate >= gate_min (gate nullable)
+  const uint16_t* Gp; int64_t g_plane;                    // dgemm3.hip: B as three fragment-major bf16 planes (nullable)
 };
 void launch_dgemm(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, bool b_transposed, hipStream_t s);
 // NT product with LDS-staged 64 x tile_n tiles, tile_n = 64 | 32 (block map: local = tile index over
@@ -174,6 +175,15 @@ void launch_dgemm(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nbloc
 void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n = 64);
 // C <- coef[0]*C + coef[1]*P over M x ldc elements; block map: local = chunk of 1024 elements
 void launch_daxpby(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
+// dgemm3.hip: the same NT products with B = G at fp32 accuracy on the bf16 matrix cores (three-plane split).
+// Block map: local = tile index over (M/32) x ceil(N/128); modes 0, 1, 2; d.Gp = planes written by launch_gplanes.
+struct GPlaneDesc {
+  const double* Gm; int32_t ldg;          // Gram image [16*nt][ldg], zero padded
+  int32_t nt, ks;                         // 16-row tiles, 32-column k-steps
+  uint16_t* out; int64_t plane;           // [3][nt][ks][64][8] bf16, plane stride in elements
+};
+void launch_gplanes(const GPlaneDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);   // local = 4 fragment blocks
+void launch_dgemm3(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
 
 // ---------------------------------------------------------------- Cholesky QR of a block (chol.hip)
 // C = R^T R of an n x n Gram matrix (n multiple of 16, <= 256), one workgroup per problem, upper tiles resident in
@@ -204,7 +214,10 @@ struct FiltState {
   int32_t bad;                // sticky failure word (pivot breakdown, degenerate bounds, failed verification)
   int32_t stage;
   int32_t products;           // block products with G this run (stage-0 product, recurrence steps, final T)
+  int32_t products_fast;      // ... of which at fp32 accuracy on the bf16 matrix cores (dgemm3.hip)
+  int32_t precise_stages;     // filter stages run in fp64 so far: a problem may not finish before it had one
   double logamp;              // accumulated log-amplification of the boundary Ritz vector relative to the damped part
+  double logamp_precise;      // ... the share of it contributed by fp64 stages
   double coef1[2];            // first step of a stage:  Y1 = coef1[0]*T + coef1[1]*Q           (T = G Q)
   double coefk[3];            // later steps: Y_{k+1} = coefk[0]*G*Y_k + coefk[1]*Y_k + coefk[2]*Y_{k-1}
   double b, lr, l1;           // bounds used by the last stage (diagnostics)
@@ -231,9 +244,12 @@ struct FiltParams {
   double log_target;          // ln(2/eps): wanted total log-amplification
   double cond_max;            // largest tolerated growth of the block's condition number per stage
   double sin_tol;             // acceptance threshold of the verification
+  double log_precise;         // log-amplification the fp64 stages must contribute once fp32-accuracy stages were used
 };
 void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s);
-void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int* verdict_pinned, hipStream_t s);
+// stage_fast: bit 0 = this stage's products run in dgemm3 (fp32 accuracy), bit 1 = the stage-0 product did
+void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int stage_fast, int* verdict_pinned,
+                      hipStream_t s);
 void launch_filt_flags(const FiltProb* probs_dev, int nprob, hipStream_t s);
 void launch_filt_theta(const FiltProb* probs_dev, int nprob, hipStream_t s);
 void launch_filt_verdict(const FiltProb* probs_dev, int nprob, FiltParams prm, int* verdict_pinned, hipStream_t s);

@@ -40,6 +40,7 @@ struct FilterTiming {
   bool on = false;
   hipEvent_t a{}, b{};
   double gemm_ms = 0.0; int gemm_launches = 0; double gemm_flops = 0.0;
+  double fast_ms = 0.0; int fast_launches = 0; double fast_flops = 0.0;      // dgemm3 launches (algorithmic flops)
 };
 
 struct FilterGroup {
@@ -52,9 +53,24 @@ struct FilterGroup {
   size_t cholA_off = 0, cholB_off = 0;       // CholDesc[nf]
   size_t solve_map_off = 0; int solve_blocks = 0;
   size_t zero_off = 0, zero_bytes = 0;       // Rayleigh-Ritz images: padding must be zero (cleared at creation)
+  // products at fp32 accuracy on the bf16 matrix cores (dgemm3.hip): planes of G + the same phases on 32 x 64 tiles
+  Phase gplanes, stage0_f, p1_f;
+  std::vector<Phase> steps_f;
+  int fast_stages = -1;                      // stages 0 .. fast_stages-1 of the next run take the fast products
   // statistics of the last run (host)
   int last_stages = 0, last_bad = 0;
 };
+
+// How many leading filter stages run at fp32 accuracy: all but the last one the group needed in its previous run
+// (the spectra of consecutive ADMM iterations are alike); none in a plan's first run.  OFF unless TADMM_FILTER_FAST=1
+// (TADMM_FILTER_FAST_STAGES=n additionally forces n): numerically validated, but on MI355X a dgemm3 launch is bound by
+// the same L2 -> CU operand traffic as the fp64 launch it replaces and is not faster yet.
+static inline int filter_fast_stages(const FilterGroup& fg) {
+  const char* on = getenv("TADMM_FILTER_FAST");
+  if (!on || !atoi(on)) return 0;          // opt-in: see DESIGN.md 5 -- per launch the fast product is not yet faster
+  if (const char* e = getenv("TADMM_FILTER_FAST_STAGES")) return std::max(0, atoi(e));
+  return std::max(0, fg.fast_stages);
+}
 
 // Rayleigh-Ritz eigen-problem of filtered problem i (appended by the caller to its eig group)
 struct FilterRR { EigDesc desc; int norm_blocks; int ext_blocks; };
@@ -74,7 +90,8 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
       d_gramA(nf), d_gramB(nf);
   std::vector<std::vector<DgemmDesc>> d_steps(std::max(0, D - 1), std::vector<DgemmDesc>(nf));
   std::vector<CholDesc> cA(nf), cB(nf);
-  std::vector<BlockRef> m_init, m_stage0, m_axpby, m_hform, m_uform, m_verify, m_emit, m_gram, m_solve;
+  std::vector<BlockRef> m_init, m_stage0, m_axpby, m_hform, m_uform, m_verify, m_emit, m_gram, m_solve, m_fast, m_gp;
+  std::vector<GPlaneDesc> d_gp(nf);
   const size_t zero_begin = align_up(ar.off, 256);
   std::vector<size_t> xth_off(nf), vh_offs(nf);
   for (int i = 0; i < nf; ++i) {   // images whose padding must be zero first, contiguous: one memset clears them
@@ -98,6 +115,14 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     const size_t rq_off = ar.take((size_t)tn * rp * 8);
     const size_t vp_off = ar.take((size_t)tn * r32 * 8);
     const size_t vh_off = vh_offs[i];                            // Ritz vectors in the block basis, rows (zero beyond r)
+    const int gnt = Npad / 16, gks = Npad / 32;                  // fragment-major bf16 planes of G (dgemm3.hip)
+    const int64_t gplane = (int64_t)gnt * gks * 512;
+    const size_t gp_off = ar.take((size_t)3 * gplane * 2);
+    {
+      GPlaneDesc& gd = d_gp[i];
+      memset(&gd, 0, sizeof gd);
+      gd.Gm = sp.G; gd.ldg = sp.ldg; gd.nt = gnt; gd.ks = gks; gd.out = (uint16_t*)dev(gp_off); gd.plane = gplane;
+    }
     const size_t ut_off = ar.take((size_t)r32 * ldy * 8);
     const size_t th_off = ar.take((size_t)r32 * 8);
     const size_t lam_off = ar.take((size_t)rp * 8);
@@ -127,6 +152,7 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
       g.selA = g.selB = g.selC = g.selP = g.selQ = -1;
       g.M = M; g.N = N_; g.K = K;
       g.tiles_m = M / 32; g.tiles_n = N_ / 32;
+      g.Gp = (const uint16_t*)dev(gp_off); g.g_plane = gplane;
       return g;
     };
     const int32_t* w_base = st ? &st->base : nullptr;
@@ -222,6 +248,8 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     const int el_blocks = (int)(((size_t)rp * ldy + 1023) / 1024);
     for (int b = 0; b < el_blocks; ++b) { m_init.push_back(BlockRef{i, b}); m_axpby.push_back(BlockRef{i, b}); }
     for (int b = 0; b < tr * tn; ++b) m_stage0.push_back(BlockRef{i, b});
+    for (int b = 0; b < (rp / 32) * ((Npad + 63) / 64); ++b) m_fast.push_back(BlockRef{i, b});   // dgemm3: 32 x 64 tiles
+    for (int b = 0; b < (gnt * gks + 3) / 4; ++b) m_gp.push_back(BlockRef{i, b});
     for (int b = 0; b < tr * ((rp + TNW - 1) / TNW); ++b) { m_gram.push_back(BlockRef{i, b}); m_hform.push_back(BlockRef{i, b}); }
     for (int b = 0; b < (r32 / 32) * (Npad / 32); ++b) m_uform.push_back(BlockRef{i, b});     // NN kernel: 32x32 tiles
     for (int b = 0; b < ((r32 + 63) / 64) * tn; ++b) m_verify.push_back(BlockRef{i, b});
@@ -240,6 +268,11 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
       xcd_by_problem(m_solve, wk);
     }
   }
+  {   // dgemm3 tiles that read the same slice of G (same problem, same column tile) go to one XCD / one L2
+    std::vector<int> tn_of(nf);
+    for (int i = 0; i < nf; ++i) tn_of[i] = (specs[i].Npad + 63) / 64;
+    xcd_by_key(m_fast, [&](const BlockRef& b) { return b.prob * 3 + b.local % tn_of[b.prob]; });
+  }
   fg.prob_off = da.take(probs.size() * sizeof(FiltProb));
   if (img) img->put(fg.prob_off, probs.data(), probs.size() * sizeof(FiltProb));
   auto place = [&](Phase& ph, const std::vector<DgemmDesc>& d, const std::vector<BlockRef>& m) {
@@ -247,6 +280,11 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
   };
   place(fg.stage0, d_stage0, m_stage0);
   place(fg.p1, d_p1, m_stage0);
+  place(fg.stage0_f, d_stage0, m_fast);
+  place(fg.p1_f, d_p1, m_fast);
+  fg.steps_f.assign(d_steps.size(), Phase());
+  for (size_t k = 0; k < d_steps.size(); ++k) place(fg.steps_f[k], d_steps[k], m_fast);
+  place_phase(fg.gplanes, da, img, d_gp.data(), d_gp.size() * sizeof(GPlaneDesc), nf, m_gp);
   place(fg.axpby, d_axpby, m_axpby);
   fg.steps.assign(d_steps.size(), Phase());
   for (size_t k = 0; k < d_steps.size(); ++k) place(fg.steps[k], d_steps[k], m_stage0);
@@ -281,6 +319,8 @@ static inline FiltParams filter_params(const FilterGroup& fg) {
   prm.log_target = log(2.0 / 1e-11);
   prm.cond_max = 1e6;
   prm.sin_tol = 1e-5;
+  prm.log_precise = log(100.0);
+  if (const char* e = getenv("TADMM_FILTER_LOG_PRECISE")) prm.log_precise = atof(e);
   if (const char* e = getenv("TADMM_FILTER_EPS")) prm.log_target = log(2.0 / atof(e));
   if (const char* e = getenv("TADMM_FILTER_COND")) prm.cond_max = atof(e);
   if (const char* e = getenv("TADMM_FILTER_SINTOL")) prm.sin_tol = atof(e);
@@ -307,13 +347,27 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
       tm->gemm_ms += ms; tm->gemm_launches += 1;
     }
   };
+  auto gemm3 = [&](const Phase& ph) {
+    const bool t = tm && tm->on;
+    if (t) (void)hipEventRecord(tm->a, s);
+    launch_dgemm3((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, s);
+    if (t) {
+      float ms = 0.f;
+      (void)hipEventRecord(tm->b, s);
+      (void)hipEventSynchronize(tm->b);
+      (void)hipEventElapsedTime(&ms, tm->a, tm->b);
+      tm->fast_ms += ms; tm->fast_launches += 1;
+    }
+  };
+  const int nfast = filter_fast_stages(fg);
+  if (nfast > 0) launch_gplanes((const GPlaneDesc*)D(fg.gplanes.desc_off), (const BlockRef*)D(fg.gplanes.map_off), fg.gplanes.nblocks, s);
   auto cholqr = [&](const Phase& gram, size_t chol_off) {
     gemm(gram);
     launch_chol_factor((const CholDesc*)D(chol_off), fg.nf, s);
     launch_chol_solve((const CholDesc*)D(chol_off), (const BlockRef*)D(fg.solve_map_off), fg.solve_blocks, s);
   };
   launch_filt_init(probs, (const BlockRef*)D(fg.init.map_off), fg.init.nblocks, fg.nf, s);
-  gemm(fg.stage0);
+  if (nfast > 0) gemm3(fg.stage0_f); else gemm(fg.stage0);
   cholqr(fg.gramB, fg.cholB_off);
   int smax = 12;
   if (const char* e = getenv("TADMM_FILTER_STAGES")) smax = std::max(1, atoi(e));
@@ -322,9 +376,10 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   // st-1 ("did anyone filter?") after stage st's product + plan launches are queued, so it never waits for the GPU;
   // the price is one stage of gated (empty) launches at the end.
   for (int st = 0; st < smax; ++st) {
-    gemm(fg.p1);
+    const bool fast = st < nfast;
+    if (fast) gemm3(fg.p1_f); else gemm(fg.p1);
     int* slot = poll.host + (size_t)(st & 1) * poll.stride;
-    launch_filt_plan(probs, fg.nf, prm, st == smax - 1, slot, s);
+    launch_filt_plan(probs, fg.nf, prm, st == smax - 1, (fast ? 1 : 0) | (nfast > 0 ? 2 : 0), slot, s);
     HIP_OK(h, hipEventRecord(poll.ev[st & 1], s));
     if (st > 0) {
       HIP_OK(h, hipEventSynchronize(poll.ev[(st - 1) & 1]));
@@ -335,10 +390,12 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
       ++stages;
     }
     launch_daxpby((const DgemmDesc*)D(fg.axpby.desc_off), (const BlockRef*)D(fg.axpby.map_off), fg.axpby.nblocks, s);
-    for (const Phase& ph : fg.steps) gemm(ph);
+    if (fast) for (const Phase& ph : fg.steps_f) gemm3(ph);
+    else for (const Phase& ph : fg.steps) gemm(ph);
     cholqr(fg.gramA, fg.cholA_off);
   }
   fg.last_stages = stages;
+  fg.fast_stages = std::max(0, stages - 1);              // next run: every stage but the last one this run needed
   cholqr(fg.gramB, fg.cholB_off);        // second pass: orthonormal to rounding
   launch_filt_flags(probs, fg.nf, s);
   gemm(fg.tfinal);
@@ -386,7 +443,8 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
         if (hipMemcpy(&st, hp[q].st, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) break;
         const double rp = hp[q].rp, np = hp[q].Npad, r32 = hp[q].r32;
         const double stages = st.stage;
-        tm->gemm_flops += 2.0 * rp * np * np * st.products          // block products with G
+        tm->fast_flops += 2.0 * rp * np * np * st.products_fast;     // block products at fp32 accuracy (algorithmic)
+        tm->gemm_flops += 2.0 * rp * np * np * (st.products - st.products_fast)   // block products with G in fp64
                           + 2.0 * rp * rp * np * (stages + 2 + 1)    // Gram of every CholQR (+ stage 0, polish) and H
                           + 2.0 * r32 * np * np;                     // residuals of the Ritz pairs
       }

@@ -145,6 +145,32 @@ static inline void xcd_by_problem(std::vector<BlockRef>& m, const std::vector<do
   m.swap(out);
 }
 
+// The same dealing with an arbitrary affinity key per block (blocks with equal key share an XCD and hence an L2): dgemm3
+// keys its tiles by (problem, column tile), so the slice of G a column tile reads is fetched into ONE L2.
+template <class KeyFn>
+static inline void xcd_by_key(std::vector<BlockRef>& m, KeyFn key) {
+  const char* e = getenv("TADMM_XCD_MAP");
+  if (e && !atoi(e)) return;
+  const int G = (int)m.size();
+  if (G < 64) return;
+  std::vector<std::vector<BlockRef>> bin(8);
+  for (const BlockRef& b : m) bin[(size_t)(key(b) & 7)].push_back(b);
+  size_t head[8] = {0};
+  std::vector<BlockRef> out;
+  out.reserve(G);
+  for (int i = 0; (int)out.size() < G; ++i) {
+    int x = i & 7;
+    if (head[x] >= bin[x].size()) {
+      int full = -1; size_t left = 0;
+      for (int y = 0; y < 8; ++y) if (bin[y].size() - head[y] > left) { left = bin[y].size() - head[y]; full = y; }
+      if (full < 0) break;
+      x = full;
+    }
+    out.push_back(bin[x][head[x]++]);
+  }
+  m.swap(out);
+}
+
 // Which Jacobi kernel a group of problems whose longest row is ld_max uses:
 // 3 = tick3 (carried self-Grams) + self pass, 1 = LDS super-pair, 0 = plain pair kernel.
 // TADMM_JACOBI_MODE (0 | 1 | 3) overrides the preference, never the capacity checks.

@@ -968,6 +968,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
   p->filt_problems = p->filt_fallbacks = p->filt_stages = 0;
   p->ftm.on = p->timing;
   p->ftm.gemm_ms = 0.0; p->ftm.gemm_launches = 0; p->ftm.gemm_flops = 0.0;
+  p->ftm.fast_ms = 0.0; p->ftm.fast_launches = 0; p->ftm.fast_flops = 0.0;
   if (p->timing) { p->ftm.a = p->ev[14]; p->ftm.b = p->ev[15]; }
   // timing helper: record a pair of events around a phase and accumulate after a sync
   auto tic = [&](int i) { if (p->timing) (void)hipEventRecord(p->ev[i], s); };
@@ -1114,6 +1115,19 @@ int tadmm_plan_filter_timing(tadmm_plan p, double out[4]) {
     return TADMM_OK;
   }
   out[0] = p->ftm.gemm_ms; out[1] = p->ftm.gemm_launches; out[2] = p->ftm.gemm_flops; out[3] = 0.0;
+  return TADMM_OK;
+}
+
+int tadmm_plan_filter_timing_fast(tadmm_plan p, double out[4]) {
+  if (!p || !out) return TADMM_ERR_INVALID;
+  if (p->lanes) {
+    double a[4], b[4];
+    tadmm_plan_filter_timing_fast(p->lanes->sub[0], a);
+    tadmm_plan_filter_timing_fast(p->lanes->sub[1], b);
+    for (int i = 0; i < 4; ++i) out[i] = a[i] + b[i];
+    return TADMM_OK;
+  }
+  out[0] = p->ftm.fast_ms; out[1] = p->ftm.fast_launches; out[2] = p->ftm.fast_flops; out[3] = 0.0;
   return TADMM_OK;
 }
 
@@ -1478,6 +1492,55 @@ int tadmm_dgemm_f64(tadmm_handle h, const double* A, const double* B, double* C,
   } else {
     launch_dgemm(gd, md, (int)map.size(), b_transposed != 0, s);
   }
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
+// C[M][N] = A[M][K] * G[N][K]^T at fp32 accuracy on the bf16 matrix cores (dgemm3.hip), the products the filter's early
+// stages use: packs G into its three fragment-major planes, then one launch.  M % 32 == 0, N = K, N % 32 == 0.
+size_t tadmm_dgemm3_scratch_bytes(int M, int N) {
+  const size_t planes = (size_t)3 * (N / 16) * (N / 32) * 512 * 2;
+  return align_up(sizeof(DgemmDesc), 256) + align_up(sizeof(GPlaneDesc), 256) + align_up(planes, 256) +
+         2 * align_up(((size_t)(M / 32) * ((N + 63) / 64) + (size_t)(N / 16) * (N / 32) / 4 + 8) * sizeof(BlockRef), 256);
+}
+
+int tadmm_dgemm3_f64(tadmm_handle h, const double* A, const double* Gm, double* C, int M, int N, int lda, int ldg, int ldc,
+                     int repeats, void* scratch, size_t scratch_bytes, void* stream_) {
+  DeviceGuard device_guard(h);
+  if (!h || !A || !Gm || !C || !scratch) return TADMM_ERR_INVALID;
+  if (M <= 0 || N <= 0 || M % 32 || N % 32 || lda < N || ldg < N || ldc < N || (lda & 1) || (ldg & 1) || (ldc & 1))
+    CTX_FAIL(h, TADMM_ERR_INVALID, "tadmm_dgemm3_f64: M, N multiples of 32, even leading dimensions >= N");
+  if (scratch_bytes < tadmm_dgemm3_scratch_bytes(M, N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "dgemm3 scratch too small");
+  hipStream_t s = (hipStream_t)stream_;
+  char* base = (char*)scratch;
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+  const size_t o_g = take(sizeof(DgemmDesc)), o_p = take(sizeof(GPlaneDesc));
+  const int nt = N / 16, ks = N / 32;
+  const int64_t plane = (int64_t)nt * ks * 512;
+  const size_t o_planes = take((size_t)3 * plane * 2);
+  std::vector<BlockRef> m_gp, m_fast;
+  for (int b = 0; b < (nt * ks + 3) / 4; ++b) m_gp.push_back(BlockRef{0, b});
+  const int tn = (N + 63) / 64;
+  for (int b = 0; b < (M / 32) * tn; ++b) m_fast.push_back(BlockRef{0, b});
+  xcd_by_key(m_fast, [&](const BlockRef& b) { return b.local % tn; });
+  const size_t o_mgp = take(m_gp.size() * sizeof(BlockRef)), o_mf = take(m_fast.size() * sizeof(BlockRef));
+  GPlaneDesc gd;
+  memset(&gd, 0, sizeof gd);
+  gd.Gm = Gm; gd.ldg = ldg; gd.nt = nt; gd.ks = ks; gd.out = (uint16_t*)(base + o_planes); gd.plane = plane;
+  DgemmDesc g;
+  memset(&g, 0, sizeof g);
+  g.A = A; g.C = C; g.selA = g.selB = g.selC = g.selP = g.selQ = -1;
+  g.M = M; g.N = N; g.K = N; g.lda = lda; g.ldb = ldg; g.ldc = ldc; g.tiles_m = M / 32; g.tiles_n = N / 32;
+  g.Gp = (const uint16_t*)(base + o_planes); g.g_plane = plane;
+  HIP_OK(h, hipMemcpyAsync(base + o_g, &g, sizeof g, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(base + o_p, &gd, sizeof gd, hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(base + o_mgp, m_gp.data(), m_gp.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipMemcpyAsync(base + o_mf, m_fast.data(), m_fast.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
+  HIP_OK(h, hipStreamSynchronize(s));
+  launch_gplanes((const GPlaneDesc*)(base + o_p), (const BlockRef*)(base + o_mgp), (int)m_gp.size(), s);
+  for (int i = 0; i < std::max(1, repeats); ++i)
+    launch_dgemm3((const DgemmDesc*)(base + o_g), (const BlockRef*)(base + o_mf), (int)m_fast.size(), s);
   HIP_OK(h, hipGetLastError());
   return TADMM_OK;
 }

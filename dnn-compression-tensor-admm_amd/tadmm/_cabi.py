@@ -87,6 +87,7 @@ ABI = {
     "tadmm_plan_set_jacobi": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int]),
     "tadmm_plan_filter_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tadmm_plan_filter_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "tadmm_plan_filter_timing_fast": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "tadmm_plan_ranks": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "tadmm_plan_lanes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tadmm_plan_destroy": (C.c_int, [C.c_void_p]),
@@ -122,6 +123,9 @@ ABI = {
     "tadmm_eigh_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                  C.POINTER(C.c_int), C.c_void_p]),
     "tadmm_dgemm_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "tadmm_dgemm3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "tadmm_dgemm3_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tadmm_dgemm_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "tadmm_cholqr_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -130,6 +130,12 @@ class ProjectionPlan:
         self.h.check(self.h.lib.tadmm_plan_filter_timing(self._plan, out))
         return dict(gemm_ms=float(out[0]), gemm_launches=int(out[1]), gemm_flops=float(out[2]))
 
+    def filter_timing_fast(self) -> dict:
+        """Instrumented runs: the filter products that ran at fp32 accuracy on the bf16 matrix cores (dgemm3_kernel)."""
+        out = (C.c_double * 4)()
+        self.h.check(self.h.lib.tadmm_plan_filter_timing_fast(self._plan, out))
+        return dict(ms=float(out[0]), launches=int(out[1]), flops=float(out[2]))
+
     def singular_values(self, layer: int, step: int) -> np.ndarray:
         r = self.ranks[layer][step + 1]
         out = (C.c_double * r)()
@@ -495,6 +501,21 @@ def dgemm(a: torch.Tensor, b: torch.Tensor, b_transposed: bool = True) -> torch.
     scratch = torch.empty(sb, dtype=torch.uint8, device=a.device)
     h.check(h.lib.tadmm_dgemm_f64(h.ptr, a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0),
                                   N, int(b_transposed), scratch.data_ptr(), sb, _stream(a.device)))
+    return out
+
+
+def dgemm3(a: torch.Tensor, g: torch.Tensor, repeats: int = 1) -> torch.Tensor:
+    """a (M, N) @ g (N, N)^T at fp32 accuracy on the bf16 matrix cores (float64 in / out): the product the early
+    stages of the filtered eigen-solver use (csrc/dgemm3.hip)."""
+    assert a.dtype == torch.float64 and g.dtype == torch.float64 and a.is_cuda and g.is_cuda
+    assert a.is_contiguous() and g.is_contiguous() and g.shape[0] == g.shape[1] == a.shape[1]
+    M, N = a.shape
+    h = Handle.get(a.device.index)
+    out = torch.empty(M, N, dtype=torch.float64, device=a.device)
+    sb = h.lib.tadmm_dgemm3_scratch_bytes(M, N)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=a.device)
+    h.check(h.lib.tadmm_dgemm3_f64(h.ptr, a.data_ptr(), g.data_ptr(), out.data_ptr(), M, N, N, N, N, repeats,
+                                   scratch.data_ptr(), sb, _stream(a.device)))
     return out
 
 

@@ -127,6 +127,10 @@ int tadmm_plan_filter_stats(tadmm_plan p, int32_t out[4]);
  * with HIP events on the launch stream: out[0] = their summed duration in ms, out[1] = number of launches,
  * out[2] = floating-point operations they executed (2*M*N*K of every product that was not gated off). */
 int tadmm_plan_filter_timing(tadmm_plan p, double out[4]);
+/* The same for the block products that ran at fp32 accuracy on the bf16 matrix cores (dgemm3_kernel: every filter
+ * stage but the last one a level needed in the previous run; TADMM_FILTER_FAST=0 keeps all products in fp64):
+ * out[0] = ms, out[1] = launches, out[2] = ALGORITHMIC flops 2*M*N*K (six bf16 products are executed per flop pair). */
+int tadmm_plan_filter_timing_fast(tadmm_plan p, double out[4]);
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
 /* Lanes.  A plan whose table mixes long chains of eigen-solves (e.g. the 3x3 kernels of ResNet layer3/layer4) with
@@ -258,6 +262,12 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
 size_t tadmm_dgemm_scratch_bytes(int M, int N);
 int tadmm_dgemm_f64(tadmm_handle h, const double* A, const double* B, double* C, int M, int N, int K, int lda, int ldb,
                     int ldc, int b_transposed, void* scratch, size_t scratch_bytes, void* stream);
+/* C[M][N] = A[M][N] * G[N][N]^T at fp32 accuracy on the bf16 matrix cores (csrc/dgemm3.hip: the block products of the
+ * filter's early stages; every value rounded to fp32 and split exactly into three bf16 terms, six MFMA products per
+ * fp32 product).  M, N multiples of 32; `repeats` launches of the product (timing). */
+size_t tadmm_dgemm3_scratch_bytes(int M, int N);
+int tadmm_dgemm3_f64(tadmm_handle h, const double* A, const double* G, double* C, int M, int N, int lda, int ldg, int ldc,
+                     int repeats, void* scratch, size_t scratch_bytes, void* stream);
 /* Cholesky QR of a block stored as its transposed image YT[n][ldy] (row j = column j, `ncols` entries): on return the
  * rows are orthonormal (one pass: to ~cond^2 * 1e-16).  *bad_out_host = 1 when a pivot broke down (numerically
  * rank-deficient block; YT is then unspecified).  n multiple of 32, <= 256; ncols multiple of 64.  Synchronous. */

@@ -139,3 +139,62 @@ def test_filtered_cores_match_full_solve(dev, monkeypatch):
         assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
     for a, b in zip(sv_f, sv_n):
         np.testing.assert_allclose(a, b, rtol=1e-9)
+
+
+def test_dgemm3_three_plane_product_matches_fp64(dev):
+    """csrc/dgemm3.hip: A G^T with every value rounded to fp32 and split exactly into three bf16 terms, six bf16 MFMA
+    products per fp32 product: accuracy of an fp32 GEMM (a few 1e-7 of the largest output) at the filter's shapes,
+    including N % 64 == 32 (surplus column tile) and N / 32 odd (zero-filled half chunk)."""
+    from tadmm import ops
+    g0 = torch.Generator().manual_seed(11)
+    for M, N in ((256, 1152), (192, 480), (64, 288), (32, 32)):
+        a = torch.randn(M, N, generator=g0, dtype=torch.float64).to(dev)
+        w = torch.randn(N, 2 * N, generator=g0, dtype=torch.float64).to(dev)
+        g = (w @ w.t()).contiguous()
+        ref = a @ g.t()
+        got = ops.dgemm3(a, g)
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert err < 5e-6, (M, N, err)
+        f32 = (a.float() @ g.float().t()).double()
+        assert err < 4 * ((f32 - ref).abs().max() / ref.abs().max()).item() + 1e-7      # no worse than an fp32 GEMM
+
+
+def test_fp32_accuracy_filter_stages_are_opt_in_and_verified(dev, monkeypatch):
+    """TADMM_FILTER_FAST=1: the early filter stages take the three-plane bf16 products (all stages but the last one the
+    level needed in the previous run); every problem still passes the fp64 verification (no fallbacks) and Z agrees with
+    the all-fp64 run far inside the parity bar."""
+    from tadmm import ops, workloads
+    from tadmm._cabi import KIND_TT_CONV
+    model, hp, _ = workloads.build("resnet50_tt", seed=5)
+    names = [n for n, _ in model.named_parameters() if n.startswith("layer4.") or n.startswith("layer3.0")]
+
+    def run(nrun):
+        ls = []
+        for n, p in model.named_parameters():
+            if n not in names:
+                continue
+            w = p.detach().to(dev).contiguous()
+            ls.append(dict(kind=KIND_TT_CONV, W=w, U=torch.zeros_like(w), Z=torch.zeros_like(w),
+                           tt_shapes=list(hp.tt_shapes[n]), ranks=list(hp.ranks[n])))
+        pl = ops.ProjectionPlan(ls)
+        stats = None
+        for _ in range(nrun):
+            pl.run(update_u=False)
+            stats = pl.filter_stats()
+        torch.cuda.synchronize()
+        pl.enable_timing(True)
+        pl.run(update_u=False)
+        fast = pl.filter_timing_fast()
+        z = [L["Z"].clone() for L in ls]
+        pl.close()
+        return z, stats, fast
+
+    z_ref, st_ref, fast_ref = run(2)
+    assert fast_ref["launches"] == 0 and st_ref["fallbacks"] == 0          # default: every product in fp64
+    monkeypatch.setenv("TADMM_FILTER_FAST", "1")
+    z_fast, st_fast, fast = run(3)
+    assert fast["launches"] > 0 and fast["flops"] > 0
+    assert st_fast["fallbacks"] == 0 and st_fast["solves"] == st_ref["solves"]
+    for a, b in zip(z_fast, z_ref):
+        rel = ((a.double() - b.double()).norm() / b.double().norm()).item()
+        assert rel < 1e-6, rel
