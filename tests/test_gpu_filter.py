@@ -189,6 +189,8 @@ def test_fp32_accuracy_filter_stages_are_opt_in_and_verified(dev, monkeypatch):
         pl.close()
         return z, stats, fast
 
+    monkeypatch.delenv("TADMM_FILTER_FAST", raising=False)
+    monkeypatch.delenv("TADMM_FILTER_FAST_STAGES", raising=False)
     z_ref, st_ref, fast_ref = run(2)
     assert fast_ref["launches"] == 0 and st_ref["fallbacks"] == 0          # default: every product in fp64
     monkeypatch.setenv("TADMM_FILTER_FAST", "1")

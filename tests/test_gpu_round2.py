@@ -328,3 +328,32 @@ def test_two_lane_plan_equals_one_lane_plan(dev, monkeypatch):
     np.testing.assert_allclose(r2.cpu().numpy(), r1.cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(sv, sv1, rtol=1e-9)
     p1.close()
+
+
+def test_two_lane_plans_can_be_created_and_destroyed_repeatedly(dev):
+    """A two-lane plan owns two streams and a worker thread: creating, running and destroying many of them (one per
+    ADMM object / epoch in a training script) must neither hang nor leak threads."""
+    import threading
+    from tadmm import ops, workloads
+    from tadmm._cabi import KIND_TT_CONV
+    model, hp, _ = workloads.build("resnet18_tt", seed=1)
+    ls = []
+    for n, p in model.named_parameters():
+        w = p.detach().to(dev).contiguous()
+        ls.append(dict(kind=KIND_TT_CONV, W=w, U=torch.zeros_like(w), Z=torch.zeros_like(w),
+                       tt_shapes=list(hp.tt_shapes[n]), ranks=list(hp.ranks[n])))
+    before = threading.active_count()
+    ref = None
+    for it in range(6):
+        pl = ops.ProjectionPlan(ls)
+        assert max(pl.lanes()) == 1
+        r = pl.run(update_u=False).clone()
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = r
+        else:
+            assert torch.equal(r, ref)                      # same plan, same inputs: bitwise the same residuals
+        if it % 2:
+            pl.close()                                      # explicit and implicit (garbage-collected) destruction
+        del pl
+    assert threading.active_count() == before               # the workers are native threads and are joined in destroy
