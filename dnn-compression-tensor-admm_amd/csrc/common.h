@@ -151,6 +151,18 @@ struct ChainDesc {
 };
 int launch_tt_chain(const ChainDesc& d, int dtype, int tile_tokens, hipStream_t s);
 
+// factorised convolution of a small image in one launch (convchain.hip): 1x1 / chain-in, k x k core, 1x1 / chain-out
+struct ConvChainDesc {
+  const void* X; void* Y;
+  const uint16_t* W1; const uint16_t* W2; const uint16_t* W3;   // fragment-major bf16 planes
+  const float* bias;
+  int64_t w1_plane, w2_plane, w3_plane;
+  int32_t B, C, R1, R2, Nout;                                   // R1 % 32 == 0, R2 % 64 == 0 (zero padded), <= 256
+  int32_t H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
+  int32_t x_vec;
+};
+int launch_tt_conv(const ConvChainDesc& d, int dtype, hipStream_t s);
+
 // ---------------------------------------------------------------- grouped GEMM (fp64 MFMA) -- filtered eigen-solver
 // See dgemm.hip.  M, N multiples of 32, K multiple of 16; every leading dimension even (16-byte rows).
 struct DgemmDesc {

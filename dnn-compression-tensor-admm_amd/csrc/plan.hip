@@ -1302,6 +1302,43 @@ int tadmm_ttconv_chain_in(tadmm_handle h, const tadmm_chain_desc* d, void* s) { 
 int tadmm_ttconv_chain_out(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 0, "ttconv_chain_out", s); }
 int tadmm_tucker_1x1(tadmm_handle h, const tadmm_chain_desc* d, void* s) { return chain_entry(h, d, 0, "tucker_1x1", s); }
 
+int tadmm_conv_chain_desc_bytes(void) { return (int)sizeof(tadmm_conv_chain_desc); }
+
+int tadmm_ttconv_fused(tadmm_handle h, const tadmm_conv_chain_desc* c, void* stream_) {
+  DeviceGuard device_guard(h);
+  if (!h || !c) return TADMM_ERR_INVALID;
+  if (!c->X || !c->Y || !c->W1 || !c->W2 || !c->W3) CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: null operand");
+  if (c->dtype != TADMM_CHAIN_F32 && c->dtype != TADMM_CHAIN_BF16) CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: bad dtype");
+  if (c->B < 0 || c->C <= 0 || c->Nout <= 0 || c->H <= 0 || c->W <= 0 || c->kh <= 0 || c->kw <= 0 || c->stride_h <= 0 ||
+      c->stride_w <= 0 || c->dil_h <= 0 || c->dil_w <= 0 || c->pad_h < 0 || c->pad_w < 0)
+    CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: bad geometry");
+  const int ho = (c->H + 2 * c->pad_h - c->dil_h * (c->kh - 1) - 1) / c->stride_h + 1;
+  const int wo = (c->W + 2 * c->pad_w - c->dil_w * (c->kw - 1) - 1) / c->stride_w + 1;
+  if (ho != c->Ho || wo != c->Wo) CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: output size does not match the geometry");
+  if (c->H * c->W > 64 || ho * wo > 64 || ho <= 0 || wo <= 0)
+    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: planes of more than 64 pixels take the three-launch path");
+  if (c->R1 <= 0 || c->R2 <= 0 || c->R1 % 32 || c->R2 % 64 || c->R1 > 256 || c->R2 > 256)
+    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: ranks must be padded to 32 / 64 and at most 256");
+  const int64_t taps = (int64_t)c->kh * c->kw;
+  if ((((uintptr_t)c->W1) & 15) || (((uintptr_t)c->W2) & 15) || (((uintptr_t)c->W3) & 15) || (((uintptr_t)c->bias) & 15) ||
+      c->w1_plane < (int64_t)(c->R1 / 16) * ((c->C + 31) / 32) * 512 || c->w2_plane < (int64_t)(c->R2 / 16) * taps * (c->R1 / 32) * 512 ||
+      c->w3_plane < (int64_t)((c->Nout + 15) / 16) * (c->R2 / 32) * 512)
+    CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: weight planes too small or misaligned");
+  ConvChainDesc d;
+  memset(&d, 0, sizeof d);
+  d.X = c->X; d.Y = c->Y; d.W1 = (const uint16_t*)c->W1; d.W2 = (const uint16_t*)c->W2; d.W3 = (const uint16_t*)c->W3;
+  d.bias = c->bias; d.w1_plane = c->w1_plane; d.w2_plane = c->w2_plane; d.w3_plane = c->w3_plane;
+  d.B = c->B; d.C = c->C; d.R1 = c->R1; d.R2 = c->R2; d.Nout = c->Nout;
+  d.H = c->H; d.W = c->W; d.Ho = ho; d.Wo = wo; d.kh = c->kh; d.kw = c->kw; d.sh = c->stride_h; d.sw = c->stride_w;
+  d.ph = c->pad_h; d.pw = c->pad_w; d.dh = c->dil_h; d.dw = c->dil_w;
+  const int epl = c->dtype == TADMM_CHAIN_F32 ? 4 : 8;
+  d.x_vec = ((c->H * c->W) % epl == 0 && (((uintptr_t)c->X) & 15) == 0) ? 1 : 0;
+  if (launch_tt_conv(d, c->dtype, (hipStream_t)stream_) != 0)
+    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: the intermediates do not fit the LDS");
+  HIP_OK(h, hipGetLastError());
+  return TADMM_OK;
+}
+
 // ---- standalone Gram / eigh (tests, Tucker path) ----
 static void gram_geom(int m, int n, StepGeom& st) {
   st.m = m; st.cols = n; st.trans = m > n;

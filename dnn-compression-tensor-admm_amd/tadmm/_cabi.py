@@ -66,6 +66,18 @@ class ChainDesc(C.Structure):
     ]
 
 
+class ConvChainDesc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("Y", C.c_void_p), ("W1", C.c_void_p), ("W2", C.c_void_p), ("W3", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("w1_plane", C.c_int64), ("w2_plane", C.c_int64), ("w3_plane", C.c_int64),
+        ("B", C.c_int32), ("C", C.c_int32), ("R1", C.c_int32), ("R2", C.c_int32), ("Nout", C.c_int32),
+        ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("stride_h", C.c_int32), ("stride_w", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+        ("dil_h", C.c_int32), ("dil_w", C.c_int32), ("dtype", C.c_int32),
+    ]
+
+
 CHAIN_F32, CHAIN_BF16 = 0, 1
 
 # name -> (restype, argtypes); this table IS the list of symbols include/tadmm.h declares
@@ -110,6 +122,8 @@ ABI = {
     "tadmm_gemm_bf16_nt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "tadmm_chain_desc_bytes": (C.c_int, []),
+    "tadmm_conv_chain_desc_bytes": (C.c_int, []),
+    "tadmm_ttconv_fused": (C.c_int, [C.c_void_p, C.POINTER(ConvChainDesc), C.c_void_p]),
     "tadmm_ttlinear_fwd": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
     "tadmm_ttlinear_bwd": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
     "tadmm_ttconv_chain_in": (C.c_int, [C.c_void_p, C.POINTER(ChainDesc), C.c_void_p]),
@@ -179,6 +193,8 @@ def load():
         if lib.tadmm_chain_desc_bytes() != C.sizeof(ChainDesc):
             raise TadmmLibraryError(f"{path}: tadmm_chain_desc layout mismatch (library {lib.tadmm_chain_desc_bytes()} "
                                     f"bytes, binding {C.sizeof(ChainDesc)})")
+        if lib.tadmm_conv_chain_desc_bytes() != C.sizeof(ConvChainDesc):
+            raise TadmmLibraryError(f"{path}: tadmm_conv_chain_desc layout mismatch")
         _lib = lib
         return lib
 

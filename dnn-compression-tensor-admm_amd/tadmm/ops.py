@@ -454,6 +454,81 @@ def chain_single(x, w_planes, bias, n_out: int, entry: str = "tadmm_ttconv_chain
     return _chain_call(entry, x, w_planes, None, bias, kin, n_out, 0, image_out, tile_tokens, prepare_only)
 
 
+def conv_chain_fits(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation) -> bool:
+    """True when the one-launch factorised convolution (csrc/convchain.hip) applies: planes of at most 64 pixels, ranks
+    at most 256 and both intermediates inside the 160 KiB of LDS."""
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    H, W = x.shape[2], x.shape[3]
+    ho = (H + 2 * padding[0] - dilation[0] * (kernel_size[0] - 1) - 1) // stride[0] + 1
+    wo = (W + 2 * padding[1] - dilation[1] * (kernel_size[1] - 1) - 1) // stride[1] + 1
+    if H * W > 64 or ho * wo > 64 or ho <= 0 or wo <= 0:
+        return False
+    r1p, r2p = -(-r1 // 32) * 32, -(-r2 // 64) * 64
+    if r1p > 256 or r2p > 256:
+        return False
+    planes, kc = (3, 64) if x.dtype == torch.float32 else (1, 128)
+    lds = (2 * planes * 64 * (kc + 8) + planes * 64 * (r1p + 8) + planes * 64 * (r2p + 8)) * 2
+    return lds <= 160 * 1024
+
+
+def conv_core_planes(core: torch.Tensor, planes: int) -> torch.Tensor:
+    """(r2, r1, kh, kw) core kernel -> fragment-major planes of the (r2 x kh*kw*r1p) tap-major matrix convchain.hip
+    multiplies with (r1p = r1 rounded up to 32, rows rounded up to 64)."""
+    r2, r1, kh, kw = core.shape
+    r1p = -(-r1 // 32) * 32
+    m = torch.zeros(r2, kh * kw, r1p, dtype=torch.float32, device=core.device)
+    m[:, :, :r1] = core.detach().float().permute(0, 2, 3, 1).reshape(r2, kh * kw, r1)
+    return weight_planes(m.reshape(r2, kh * kw * r1p), planes, pad_rows=64)
+
+
+def conv_chain(x: torch.Tensor, w1p: torch.Tensor, w2p: torch.Tensor, w3p: torch.Tensor, bias, n_out: int, kernel_size,
+               stride, padding, dilation) -> torch.Tensor:
+    """y (B, n_out, Ho, Wo) = W3 conv_kxk(W1 x; Wc) + bias for small NCHW images in one launch (`tadmm_ttconv_fused`).
+    w1p = weight_planes(W1, P, pad_rows=32), w2p = conv_core_planes(core, P), w3p = weight_planes(W3, P, pad_cols=64)."""
+    if not x.is_cuda:
+        raise TadmmError(-1, "x must live on a HIP device; there is no CPU path")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        bias = bias.detach().float().contiguous()
+        bias_key = None
+    else:
+        bias_key = 0 if bias is None else bias.data_ptr()
+    key = ("conv", tuple(x.shape), x.dtype, x.device, w1p.data_ptr(), w2p.data_ptr(), w3p.data_ptr(), bias_key, n_out,
+           tuple(kernel_size), tuple(stride), tuple(padding), tuple(dilation))
+    memo = _CHAIN_MEMO.get(key) if bias_key is not None else None
+    if memo is None:
+        B, Cc, H, W = x.shape
+        d = _cabi.ConvChainDesc()
+        d.dtype = _cabi.CHAIN_F32 if x.dtype == torch.float32 else _cabi.CHAIN_BF16
+        ho = (H + 2 * padding[0] - dilation[0] * (kernel_size[0] - 1) - 1) // stride[0] + 1
+        wo = (W + 2 * padding[1] - dilation[1] * (kernel_size[1] - 1) - 1) // stride[1] + 1
+        d.W1, d.W2, d.W3 = w1p.data_ptr(), w2p.data_ptr(), w3p.data_ptr()
+        d.bias = None if bias is None else bias.data_ptr()
+        d.w1_plane, d.w2_plane, d.w3_plane = w1p[0].numel(), w2p[0].numel(), w3p[0].numel()
+        d.B, d.C, d.R1, d.R2, d.Nout = B, Cc, w1p.shape[1] * 16, w2p.shape[1] * 16, n_out
+        d.H, d.W, d.Ho, d.Wo, d.kh, d.kw = H, W, ho, wo, kernel_size[0], kernel_size[1]
+        d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w = (stride[0], stride[1], padding[0], padding[1],
+                                                                      dilation[0], dilation[1])
+        if (w2p.shape[2] * 32 != kernel_size[0] * kernel_size[1] * d.R1 or w3p.shape[2] * 32 != d.R2
+                or w1p.shape[2] != -(-Cc // 32)):
+            raise TadmmError(-1, "conv chain: weight planes do not match each other")
+        dev = x.device
+        h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        memo = (d, h.lib.tadmm_ttconv_fused, h, (B, n_out, ho, wo), (w1p, w2p, w3p, bias))
+        if bias_key is not None:
+            if len(_CHAIN_MEMO) >= 1024:
+                _CHAIN_MEMO.clear()
+            _CHAIN_MEMO[key] = memo
+    d, fn, h, yshape, _ = memo
+    y = torch.empty(yshape, dtype=x.dtype, device=x.device)
+    d.X, d.Y = x.data_ptr(), y.data_ptr()
+    if yshape[0] > 0:
+        h.check(fn(h.ptr, C.byref(d), _stream(x.device)))
+    return y
+
+
 # ------------------------------------------------------------------ Gram / eigh (tests, Tucker)
 def gram(a: torch.Tensor):
     """fp64 Gram of a float32 (m,n) matrix: A A^T if m<=n else A^T A.  Returns (N,N) float64."""

@@ -23,6 +23,7 @@ from torch.nn import init
 from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
 
 from . import functional as HF
+from . import ops
 from . import tucker
 
 
@@ -114,8 +115,25 @@ class TKConv2dC(_TKConvBase):
         f3 = HF.pointwise(f2, w3, self.bias, "tadmm_tucker_1x1", p3)
         return f1, f2, f3
 
+    def _fused(self, x, w1, core, w3):
+        """The whole layer in one launch when the planes are small (csrc/convchain.hip); None when it does not apply."""
+        if torch.is_grad_enabled() or self.groups != 1 or not ops.conv_chain_fits(
+                x, w1.shape[0], w3.shape[1], self.kernel_size, self.stride, self.padding, self.dilation):
+            return None
+        n = 1 if x.dtype == torch.bfloat16 else 3
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        key = (n, x.device, w1._version, core._version, w3._version)
+        if cache.get("key") != key:
+            cache.update(key=key, planes=(ops.weight_planes(w1.detach(), n, pad_rows=32), ops.conv_core_planes(core, n),
+                                          ops.weight_planes(w3.detach(), n, pad_cols=64)))
+        p1, p2, p3 = cache["planes"]
+        return ops.conv_chain(x, p1, p2, p3, self.bias, self.out_channels, self.kernel_size, self.stride, self.padding,
+                              self.dilation)
+
     def forward(self, x):
-        return self._stages(x)[2]
+        y = self._fused(x, self.first_kernel.reshape(self.in_rank, self.in_channels), self.core_kernel,
+                        self.last_kernel.reshape(self.out_channels, self.out_rank))
+        return y if y is not None else self._stages(x)[2]
 
     def forward_features(self, x):                                # TKConv.py:100-109
         f1, f2, f3 = self._stages(x)
@@ -168,6 +186,9 @@ class TKConv2dM(_TKConvBase):
             init.xavier_uniform_(p)
 
     def forward(self, x: Tensor) -> Tensor:                       # TKConv.py:210-214
+        y = TKConv2dC._fused(self, x, self.first_factor, self.core_kernel, self.last_factor)
+        if y is not None:
+            return y
         grad = torch.is_grad_enabled()
         cache = None if grad else self.__dict__.setdefault("_plane_cache", {})
         n = 1 if x.dtype == torch.bfloat16 else 3

@@ -29,6 +29,7 @@ from torch.nn import init
 from torch.nn.modules.utils import _pair, _reverse_repeat_tuple
 
 from . import functional as HF
+from . import ops
 from . import ttd
 from ._cabi import KIND_TT_CONV, KIND_TT_LINEAR
 
@@ -172,12 +173,22 @@ class TTConv2dM(_TTConvBase):
             p_in = p_out = None
         else:
             cache = self.__dict__.setdefault("_chain_cache", {})
-            key = (n, x.device, tuple(p._version for p in params))
+            key = (n, x.device, tuple(p._version for p in params), self.core_kernel._version)
             if cache.get("key") != key:
                 with torch.no_grad():
                     w_in, w_out = self._factors()
                 cache.update(key=key, w=(w_in, w_out), planes=(HF.planes_of(w_in, n), HF.planes_of(w_out, n)))
             (w_in, w_out), (p_in, p_out) = cache["w"], cache["planes"]
+        if not grad and self.groups == 1 and ops.conv_chain_fits(x, w_in.shape[0], w_out.shape[1], self.kernel_size,
+                                                                  self.stride, self.padding, self.dilation):
+            # small planes (<= 64 pixels): the whole layer in ONE launch, both intermediates in LDS (csrc/convchain.hip)
+            fkey = (key, "fused")
+            if cache.get("fkey") != fkey:
+                cache.update(fkey=fkey, fplanes=(ops.weight_planes(w_in, n, pad_rows=32), ops.conv_core_planes(self.core_kernel, n),
+                                                 ops.weight_planes(w_out, n, pad_cols=64)))
+            f1, f2, f3 = cache["fplanes"]
+            return ops.conv_chain(x, f1, f2, f3, self.bias, self.out_channels, self.kernel_size, self.stride, self.padding,
+                                  self.dilation)
         out = HF.pointwise(x, w_in, None, "tadmm_ttconv_chain_in", p_in)
         core = self.core_kernel if x.dtype == self.core_kernel.dtype else self.core_kernel.to(x.dtype)
         out = F.conv2d(out, core, None, self.stride, self.padding, self.dilation, self.groups)

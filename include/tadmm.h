@@ -240,6 +240,24 @@ int tadmm_ttconv_chain_out(tadmm_handle h, const tadmm_chain_desc* d, void* stre
 /* TKConv2dC first / last 1x1 stage (TKConv.py:93-98): per-pixel channel mixing, single product. */
 int tadmm_tucker_1x1(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
 
+/* The whole factorised convolution of a SMALL image in one launch (csrc/convchain.hip): y = W3 conv_kxk(W1 x; Wc) + bias
+ * for NCHW tensors whose input and output planes have at most 64 pixels; the two intermediates stay in LDS.  TTConv2dM
+ * (TTConv.py:130-153), TKConv2dC / TKConv2dM (TKConv.py:93-98, :210-214).  W1 (R1 x C), W2 (R2 x kh*kw*R1, tap-major:
+ * column (dy*kw + dx)*R1 + c) and W3 (Nout x R2) are fragment-major bf16 planes as for tadmm_chain_desc, R1 a multiple of
+ * 32 and R2 of 64 (zero padded), both <= 256; groups = 1.  Returns TADMM_ERR_UNSUPPORTED when the image or the
+ * intermediates do not fit (the caller then uses tadmm_ttconv_chain_in / conv2d / tadmm_ttconv_chain_out). */
+typedef struct {
+  const void* X; void* Y;
+  const void* W1; const void* W2; const void* W3;
+  const float* bias;
+  int64_t w1_plane, w2_plane, w3_plane;
+  int32_t B, C, R1, R2, Nout;
+  int32_t H, W, Ho, Wo, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+  int32_t dtype;                              /* TADMM_CHAIN_F32 | TADMM_CHAIN_BF16 */
+} tadmm_conv_chain_desc;
+int tadmm_conv_chain_desc_bytes(void);
+int tadmm_ttconv_fused(tadmm_handle h, const tadmm_conv_chain_desc* d, void* stream);
+
 /* G = A A^T (m<=n) or A^T A (m>n) of a row-major float32 m x n matrix, exact fp32 products
  * accumulated in fp64 on v_mfma_f64_16x16x4_f64.  G is written as double[Npad][ldg] (zero padded; see tadmm_gram_ld), N=min(m,n).
  * partial_dev: scratch of tadmm_gram_scratch_bytes(m,n). */

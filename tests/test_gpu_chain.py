@@ -173,3 +173,71 @@ def test_ttlinearm_fused_backward_matches_fp64_autograd():
     assert (lin.bias.grad.double() - bd.grad).abs().max().item() < 1e-5 * bd.grad.abs().max().item()
     for c, cd in zip(lin.tt_cores, cores):
         assert (c.grad.double() - cd.grad).abs().max().item() < 2e-5 * cd.grad.abs().max().item()
+
+
+# ------------------------------------------------------------------ fused factorised convolution (csrc/convchain.hip)
+@pytest.mark.parametrize("B,C,H,W,r1,r2,O,k,stride,pad,dil", [
+    (8, 64, 8, 8, 23, 25, 64, 3, 1, 1, 1),       # TKConv2dC ResNet-32 layer3 (CIFAR)
+    (5, 96, 7, 7, 40, 36, 80, 3, 1, 1, 1),       # 49 pixels: scalar loads, ragged ranks
+    (3, 32, 8, 8, 16, 20, 24, 3, 2, 1, 1),       # stride 2: 8x8 -> 4x4
+    (2, 48, 6, 6, 24, 24, 40, 5, 1, 2, 1),       # 5x5 taps
+    (2, 32, 7, 7, 12, 12, 16, 3, 1, 2, 2),       # dilation 2
+    (4, 40, 5, 5, 9, 11, 12, 1, 1, 0, 1),        # 1x1 core
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_chain_matches_three_torch_convs(B, C, H, W, r1, r2, O, k, stride, pad, dil, dtype):
+    import torch.nn.functional as F
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(B * C + k)
+    x = torch.randn(B, C, H, W, generator=g).cuda().to(dtype)
+    w1 = (torch.randn(r1, C, generator=g) / C ** 0.5).cuda()
+    core = (torch.randn(r2, r1, k, k, generator=g) / (r1 * k * k) ** 0.5).cuda()
+    w3 = (torch.randn(O, r2, generator=g) / r2 ** 0.5).cuda()
+    bias = torch.randn(O, generator=g).cuda()
+    n = 3 if dtype == torch.float32 else 1
+    ks, st, pd, dl = (k, k), (stride, stride), (pad, pad), (dil, dil)
+    assert ops.conv_chain_fits(x, r1, r2, ks, st, pd, dl)
+    p1, p2, p3 = ops.weight_planes(w1, n, pad_rows=32), ops.conv_core_planes(core, n), ops.weight_planes(w3, n, pad_cols=64)
+    y = ops.conv_chain(x, p1, p2, p3, bias, O, ks, st, pd, dl)
+    # reference in fp64 on the weights the kernel sees (bf16 mode: rounded to bf16)
+    q = (lambda t: t.double()) if dtype == torch.float32 else (lambda t: t.to(torch.bfloat16).double())
+    xd = x.double()
+    ref = F.conv2d(xd, q(w1).view(r1, C, 1, 1))
+    ref = F.conv2d(ref, q(core), None, st, pd, dl)
+    ref = F.conv2d(ref, q(w3).view(O, r2, 1, 1), bias.double())
+    assert y.shape == ref.shape and y.dtype == dtype
+    err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (3e-6 if dtype == torch.float32 else 3e-2), err
+
+
+def test_small_image_conv_layers_take_the_fused_launch(monkeypatch):
+    """TTConv2dM / TKConv2dC / TKConv2dM in inference on planes of <= 64 pixels: one `tadmm_ttconv_fused` launch, equal to
+    the three-launch path (the path training and larger images take)."""
+    from tadmm import ops, tk_layers, tt_layers
+    torch.manual_seed(3)
+    hp = _HP()
+    hp.tt_shapes = {"c.weight": [8, 8, 9, 8, 8]}
+    hp.ranks = {"c.weight": [1, 8, 40, 40, 8, 1]}
+    conv = tt_layers.TTConv2dM(64, 64, 3, padding=1, bias=True, hp_dict=hp, name="c.weight").cuda()
+    with torch.no_grad():
+        conv.bias.normal_()
+    hk = _HP()
+    hk.ranks = {"k.weight": [25, 23]}
+    tkc = tk_layers.TKConv2dC(64, 64, 3, padding=1, bias=True, hp_dict=hk, name="k.weight").cuda()
+    tkm = tk_layers.TKConv2dM(64, 64, 3, padding=1, bias=True, hp_dict=hk, name="k.weight").cuda()
+    x = torch.randn(16, 64, 8, 8, device="cuda")
+    calls = []
+    real = ops.conv_chain
+    monkeypatch.setattr(ops, "conv_chain", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for layer in (conv, tkc, tkm):
+        n0 = len(calls)
+        with torch.no_grad():
+            y = layer(x)
+        assert len(calls) == n0 + 1
+        y3 = layer(x)                                        # grad mode: three launches, differentiable
+        assert len(calls) == n0 + 1 and y3.requires_grad
+        assert (y - y3.detach()).abs().max().item() < 5e-6 * y3.abs().max().item()
+        big = torch.randn(2, 64, 14, 14, device="cuda")      # 196 pixels: not eligible
+        with torch.no_grad():
+            layer(big)
+        assert len(calls) == n0 + 1
