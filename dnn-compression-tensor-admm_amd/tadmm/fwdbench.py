@@ -91,8 +91,10 @@ def run(device=None, iters: int = 50):
             wcd = wc.to(dtype)
             ms = _time(lambda: conv(xc), iters)
             dense = _time(lambda: F.conv2d(xc, wcd, None, 1, 1), iters)
+            one = ops.conv_chain_fits(xc, conv.in_tt_ranks[0], conv.out_tt_ranks[-1], conv.kernel_size, conv.stride,
+                                      conv.padding, conv.dilation)
             rows.append(_row("TTConv2dM resnet18 layer4.0.conv2 (B=64, 7x7, ranks %s)" % conv.tt_ranks, dtype, ms, dense,
-                             None, 0.0, 3))
+                             None, 0.0, 1 if one else 3))
         # ---- TKConv2dC: ResNet-32 layer3 3x3 (64, 64, 3, 3), x (128, 64, 8, 8)
         hp32 = HPM.fresh_table("tk_resnet32_hp.HyperParamsDictRatio3x")
         tk = tk_layers.TKConv2dC(64, 64, 3, padding=1, bias=False, hp_dict=hp32, name="layer3.1.conv1.weight").to(dev)
@@ -102,8 +104,9 @@ def run(device=None, iters: int = 50):
             wkd = wk.to(dtype)
             ms = _time(lambda: tk(xk), iters)
             dense = _time(lambda: F.conv2d(xk, wkd, None, 1, 1), iters)
+            one = ops.conv_chain_fits(xk, tk.in_rank, tk.out_rank, tk.kernel_size, tk.stride, tk.padding, tk.dilation)
             rows.append(_row("TKConv2dC resnet32 layer3.1.conv1 (B=128, 8x8, ranks [%d, %d])" % (tk.out_rank, tk.in_rank),
-                             dtype, ms, dense, None, 0.0, 3))
+                             dtype, ms, dense, None, 0.0, 1 if one else 3))
     return rows
 
 
