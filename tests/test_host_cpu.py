@@ -235,3 +235,21 @@ def test_eigen_problem_size_limit_is_reported_not_hidden():
     assert lib.tadmm_tucker_workspace_bytes(h, 1, tk, C.byref(size)) < 0
     assert "exceeds" in lib.tadmm_last_error(h).decode()
     lib.tadmm_destroy(h)
+
+
+def test_chain_eligibility_rules_are_pure_host_logic():
+    """Which forward path a layer takes is decided on the host from shapes alone (no GPU needed): the fused conv launch
+    for planes of <= 64 pixels whose intermediates fit the LDS, the fused linear chain for middle ranks <= 256."""
+    import torch
+    from tadmm import functional as HF
+    from tadmm import ops
+    x = torch.zeros(2, 64, 8, 8)
+    assert ops.conv_chain_fits(x, 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))
+    assert ops.conv_chain_fits(x.to(torch.bfloat16), 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))
+    assert not ops.conv_chain_fits(x, 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))          # three planes of 224: > 160 KiB
+    assert not ops.conv_chain_fits(torch.zeros(2, 64, 14, 14), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))   # 196 pixels
+    assert not ops.conv_chain_fits(x, 300, 25, (3, 3), (1, 1), (1, 1), (1, 1))           # rank > 256
+    assert not ops.conv_chain_fits(x.double(), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))
+    assert ops.conv_chain_fits(x, 23, 25, (3, 3), (2, 2), (1, 1), (1, 1))                 # stride 2: 8x8 -> 4x4
+    assert not ops.conv_chain_fits(x, 23, 25, (9, 9), (1, 1), (0, 0), (1, 1))             # empty output plane
+    assert HF.fused_rank_ok(256) and not HF.fused_rank_ok(257) and not HF.fused_rank_ok(0)
