@@ -159,6 +159,7 @@ struct ConvChainDesc {
   int64_t w1_plane, w2_plane, w3_plane;
   int32_t B, C, R1, R2, Nout;                                   // R1 % 32 == 0, R2 % 64 == 0 (zero padded), <= 256
   int32_t H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
+  int32_t TR, tiles, NT;                                        // output rows per workgroup, tiles per image, 64-pixel tiles of its halo
   int32_t x_vec;
 };
 int launch_tt_conv(const ConvChainDesc& d, int dtype, hipStream_t s);

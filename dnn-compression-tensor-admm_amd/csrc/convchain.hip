@@ -4,15 +4,16 @@
 //                                                     convolution, output-core chain) and TKConv2dC / TKConv2dM
 //                                                     (TKConv.py:93-98, :210-214: 1x1, k x k, 1x1)
 //
-// for images whose input and output planes have at most 64 pixels (the last stages of the CIFAR / ImageNet ResNets:
-// 8x8, 7x7, 4x4): one workgroup per image, the two intermediates (r1 and r2 channels per pixel, both <= 256) never leave
-// LDS.  Three products on the bf16 matrix cores, fp32 through the exact three-plane split (chain.hip):
+// One workgroup per TILE OF OUTPUT ROWS of an image (at most 64 output pixels: the whole plane for 8x8 / 7x7, four rows of
+// a 14x14 plane, two of a 28x28, one of a 56x56); it first builds H1 for the input rows the tile's taps reach (its halo:
+// at most 192 pixels, recomputed by the neighbouring tiles), so the two intermediates (r1 and r2 channels per pixel, both
+// <= 256) never leave LDS.  Three products on the bf16 matrix cores, fp32 through the exact three-plane split (chain.hip):
 //   1. H1[pixel][r1]  = X[pixel][C] * W1^T             tokens = input pixels, X read in place from the NCHW tensor
 //   2. H2[opixel][r2] = sum_tap H1[src(opixel, tap)][:] * Wc[tap]^T     K = taps * r1; the token fragment of a tap is the
 //      H1 row of the shifted input pixel (a per-lane LDS gather), zero outside the image (padding)
 //   3. Y[opixel][O]   = H2[opixel][r2] * W3^T + bias   written to the NCHW tensor
 // Weights are fragment-major bf16 planes (chain.hip); Wc is packed as an (r2 x taps*r1) matrix, tap-major.
-// Larger images take the three-launch path (tadmm_ttconv_chain_in, the device library's conv2d, tadmm_ttconv_chain_out).
+// Wider planes (more than 64 output columns) and intermediates beyond the LDS take the three-launch path (tadmm_ttconv_chain_in, the device library's conv2d, tadmm_ttconv_chain_out).
 #include "chain_common.h"
 
 namespace tadmm {
@@ -23,11 +24,11 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // gathered token fragments of one k-step: row src[mt] of the LDS image (or zeros), three or one plane
 template <int P>
-__device__ __forceinline__ void gather_x(bf16x8_t (&a)[P], const uint16_t* img, int ld, int row, int kloc, int q) {
+__device__ __forceinline__ void gather_x(bf16x8_t (&a)[P], const uint16_t* img, int prow, int ld, int row, int kloc, int q) {
   const int rr = row < 0 ? 0 : row;
 #pragma unroll
   for (int p = 0; p < P; ++p) {
-    bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&img[(p * kCTM + rr) * ld + 32 * kloc + 8 * q]);
+    bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(&img[(p * prow + rr) * ld + 32 * kloc + 8 * q]);
     if (row < 0) v = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
     a[p] = v;
   }
@@ -47,10 +48,10 @@ __device__ __forceinline__ void mma_tile(const bf16x8_t (&a)[P], const bf16x8_t 
   }
 }
 
-// acc (features 4q..4q+3 of token r, tile j) -> P planes of an LDS image [P][kCTM][ld]
+// acc (features 4q..4q+3 of token row0 + r, tile j) -> P planes of an LDS image [P][prow][ld]
 template <int P, int NB>
-__device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[kCTM / 16][NB], uint16_t* img, int ld, int f_base, int nfeat,
-                                           int r, int q) {
+__device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[kCTM / 16][NB], uint16_t* img, int prow, int row0, int ld,
+                                           int f_base, int nfeat, int r, int q) {
 #pragma unroll
   for (int mt = 0; mt < kCTM / 16; ++mt)
 #pragma unroll
@@ -62,7 +63,7 @@ __device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[kCTM / 16][NB]
       split2<P>(acc[mt][j][2], acc[mt][j][3], s1);
 #pragma unroll
       for (int p = 0; p < P; ++p)
-        *reinterpret_cast<uint2*>(&img[(p * kCTM + 16 * mt + r) * ld + f0]) = make_uint2(s0[p], s1[p]);
+        *reinterpret_cast<uint2*>(&img[(p * prow + row0 + 16 * mt + r) * ld + f0]) = make_uint2(s0[p], s1[p]);
     }
 }
 
@@ -71,16 +72,16 @@ __device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[kCTM / 16][NB]
 // as in the general image loader, which matters for planes whose size is not a multiple of the vector width (7x7).
 template <int P, int KC, typename T>
 __device__ __forceinline__ void conv_load(ChunkLoader<P, kCTM, KC, T, true>& ld, const T* X, int img, int C, int hw,
-                                          int k0, bool vec, int tid) {
+                                          int p_off, int k0, bool vec, int tid) {
   constexpr int EPL = 16 / sizeof(T);
 #pragma unroll
   for (int i = 0; i < ChunkLoader<P, kCTM, KC, T, true>::NV; ++i) {
     const int v = tid + 256 * i;
-    const int c = k0 + v / (kCTM / EPL), p0 = (v % (kCTM / EPL)) * EPL;
+    const int c = k0 + v / (kCTM / EPL), p0 = p_off + (v % (kCTM / EPL)) * EPL;     // p0: pixel of the plane
     const T* base = X + ((int64_t)img * C + min(c, C - 1)) * hw;
     uint4 r = make_uint4(0, 0, 0, 0);
     if (vec) {
-      if (c < C && p0 < hw) r = *reinterpret_cast<const uint4*>(base + p0);
+      if (c < C && p0 < hw) r = *reinterpret_cast<const uint4*>(base + p0);        // hw % EPL == 0: inside or outside
     } else {
       alignas(16) T e[EPL];
 #pragma unroll
@@ -100,20 +101,21 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int img = blockIdx.x;
+  const int img = blockIdx.x / d.tiles, tile = blockIdx.x - img * d.tiles;
   const int hw_in = d.H * d.W, hw_out = d.Ho * d.Wo;
+  // this workgroup's output rows and the input rows their taps reach (clipped to the image)
+  const int oy0 = tile * d.TR, orows = min(d.TR, d.Ho - oy0), n_out = orows * d.Wo;
+  const int iy_lo = max(0, oy0 * d.sh - d.ph), iy_hi = min(d.H - 1, (oy0 + orows - 1) * d.sh - d.ph + (d.kh - 1) * d.dh);
+  const int n_in = max(0, iy_hi - iy_lo + 1) * d.W, p_in0 = iy_lo * d.W;
+  const int ntt = (n_in + kCTM - 1) / kCTM;                    // token tiles of product 1 (<= d.NT)
+  const int prow1 = kCTM * d.NT;
   uint16_t* Xs = lds;                                          // [2][P][64][LDX]
   const int ld1 = d.R1 + kPad, ld2 = d.R2 + kPad;
-  uint16_t* H1s = lds + 2 * P * kCTM * LDX;                    // [P][64][ld1]
-  uint16_t* H2s = H1s + P * kCTM * ld1;                        // [P][64][ld2]
+  uint16_t* H1s = lds + 2 * P * kCTM * LDX;                    // [P][64 * NT][ld1]
+  uint16_t* H2s = H1s + P * prow1 * ld1;                       // [P][64][ld2]
 
-  // ---------------- product 1: H1 = X W1^T over the image's input pixels (chain.hip, product 1)
+  // ---------------- product 1: H1 = X W1^T over the halo's input pixels, 64 at a time (chain.hip, product 1)
   {
-    float4v_t acc[MT][NBW];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int j = 0; j < NBW; ++j) acc[mt][j] = float4v_t{0.f, 0.f, 0.f, 0.f};
     const int KS1 = (d.C + 31) / 32, nt1 = d.R1 / 16;
     gw_t w1[NBW];
 #pragma unroll
@@ -122,36 +124,46 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
       ft = ft < nt1 ? ft : nt1 - 1;
       w1[j] = (gw_t)d.W1 + ((int64_t)ft * KS1 * 64 + lane) * 8;
     }
-    ChunkLoader<P, kCTM, KC, T, true> ld;
     const int nchunks = (d.C + KC - 1) / KC;
-    // weight fragments RD1 k-steps ahead (ring indexed statically: RD1 divides the k-steps of a chunk)
-    constexpr int RD1 = (SPC % 4 == 0) ? 4 : 2;
-    bf16x8_t b[RD1][P][NBW];
-    conv_load<P, KC, T>(ld, static_cast<const T*>(d.X), img, d.C, hw_in, 0, d.x_vec != 0, tid);
+    const T* X = static_cast<const T*>(d.X);
+    for (int tt = 0; tt < ntt; ++tt) {
+      const int p_off = p_in0 + kCTM * tt;                     // first plane pixel of this token tile
+      const bool xvec = d.x_vec != 0 && (p_off % (16 / (int)sizeof(T))) == 0;
+      float4v_t acc[MT][NBW];
 #pragma unroll
-    for (int u = 0; u < RD1 - 1; ++u) load_w<P, NBW>(b[u], w1, d.w1_plane, min(u, KS1 - 1));
-    ld.store(Xs, tid);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-      const uint16_t* Xc = Xs + (c & 1) * (P * kCTM * LDX);
-      conv_load<P, KC, T>(ld, static_cast<const T*>(d.X), img, d.C, hw_in, min(c + 1, nchunks - 1) * KC, d.x_vec != 0, tid);
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int ks = 0; ks < SPC; ++ks) {
-        load_w<P, NBW>(b[(ks + RD1 - 1) % RD1], w1, d.w1_plane, min(c * SPC + ks + RD1 - 1, KS1 - 1));
+        for (int j = 0; j < NBW; ++j) acc[mt][j] = float4v_t{0.f, 0.f, 0.f, 0.f};
+      ChunkLoader<P, kCTM, KC, T, true> ld;
+      // weight fragments RD1 k-steps ahead (ring indexed statically: RD1 divides the k-steps of a chunk)
+      constexpr int RD1 = (SPC % 4 == 0) ? 4 : 2;
+      bf16x8_t b[RD1][P][NBW];
+      conv_load<P, KC, T>(ld, X, img, d.C, hw_in, p_off, 0, xvec, tid);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          bf16x8_t a[P];
-#pragma unroll
-          for (int p = 0; p < P; ++p)
-            a[p] = *reinterpret_cast<const bf16x8_t*>(&Xc[(p * kCTM + 16 * mt + r) * LDX + 32 * ks + 8 * q]);
-          mma_tile<P, NBW>(a, b[ks % RD1], acc[mt]);
-        }
-      }
-      static_assert(SPC % RD1 == 0, "fragment ring returns to slot 0 at every chunk boundary");
-      ld.store(Xs + ((c + 1) & 1) * (P * kCTM * LDX), tid);
+      for (int u = 0; u < RD1 - 1; ++u) load_w<P, NBW>(b[u], w1, d.w1_plane, min(u, KS1 - 1));
+      ld.store(Xs, tid);
       __syncthreads();
+      for (int c = 0; c < nchunks; ++c) {
+        const uint16_t* Xc = Xs + (c & 1) * (P * kCTM * LDX);
+        conv_load<P, KC, T>(ld, X, img, d.C, hw_in, p_off, min(c + 1, nchunks - 1) * KC, xvec, tid);
+#pragma unroll
+        for (int ks = 0; ks < SPC; ++ks) {
+          load_w<P, NBW>(b[(ks + RD1 - 1) % RD1], w1, d.w1_plane, min(c * SPC + ks + RD1 - 1, KS1 - 1));
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            bf16x8_t a[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+              a[p] = *reinterpret_cast<const bf16x8_t*>(&Xc[(p * kCTM + 16 * mt + r) * LDX + 32 * ks + 8 * q]);
+            mma_tile<P, NBW>(a, b[ks % RD1], acc[mt]);
+          }
+        }
+        static_assert(SPC % RD1 == 0, "fragment ring returns to slot 0 at every chunk boundary");
+        ld.store(Xs + ((c + 1) & 1) * (P * kCTM * LDX), tid);
+        __syncthreads();
+      }
+      acc_to_lds<P, NBW>(acc, H1s, prow1, kCTM * tt, ld1, wave * NBW * 16, d.R1, r, q);
     }
-    acc_to_lds<P, NBW>(acc, H1s, ld1, wave * NBW * 16, d.R1, r, q);
   }
   __syncthreads();
 
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int px = 16 * mt + r;
-      oy[mt] = px < hw_out ? px / d.Wo : -(1 << 20);          // invalid output pixels gather nothing
+      oy[mt] = px < n_out ? oy0 + px / d.Wo : -(1 << 20);     // invalid output pixels gather nothing
       ox[mt] = px - (px / d.Wo) * d.Wo;
     }
     // weight fragments RD - 1 steps ahead, ring indexed statically (RD steps per trip); surplus steps of the last trip
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
           const int iy = oy[mt] * d.sh - d.ph + dy * d.dh, ix = ox[mt] * d.sw - d.pw + dx * d.dw;
           const bool in = live && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
           bf16x8_t a[P];
-          gather_x<P>(a, H1s, ld1, in ? iy * d.W + ix : -1, ks, q);
+          gather_x<P>(a, H1s, prow1, ld1, in ? (iy - iy_lo) * d.W + ix : -1, ks, q);
           mma_tile<P, NBW>(a, b[u], acc[mt]);
         }
         ks += 1;
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
         if (tap >= taps) { tap = taps - 1; }                  // keeps the surplus steps' addresses valid
       }
     }
-    acc_to_lds<P, NBW>(acc, H2s, ld2, wave * NBW * 16, d.R2, r, q);
+    acc_to_lds<P, NBW>(acc, H2s, kCTM, 0, ld2, wave * NBW * 16, d.R2, r, q);
   }
   __syncthreads();
 
@@ -238,20 +250,23 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             bf16x8_t a[P];
-            gather_x<P>(a, H2s, ld2, t < KS3 ? 16 * mt + r : -1, min(t, KS3 - 1), q);
+            gather_x<P>(a, H2s, kCTM, ld2, t < KS3 ? 16 * mt + r : -1, min(t, KS3 - 1), q);
             mma_tile<P, NB3>(a, b[u], acc[mt]);
           }
         }
       }
-      // Stores.  The image's output block [Nout][hw] is contiguous in memory, so a group of feature rows is staged in a
-      // wave-private LDS area in exactly that layout and copied out as whole 16-byte vectors; the direct path (a lane's
-      // values one by one, 2-4 bytes each) is the fallback for unaligned blocks.
+      // Stores.  A group of feature rows is staged in a wave-private LDS area as [feature][n_out pixels] and copied out in
+      // units of 16 bytes (whole plane per workgroup: the [Nout][hw] block of the image is contiguous in memory) or
+      // 8 bytes (row tiles: every feature row of the tile is a separate run); the direct path (a lane's values one by
+      // one, 2-4 bytes each) is the fallback for unaligned runs.
       constexpr int SZ = sizeof(T);
       const int f_base = g * NB3 * 16;
       const int nf = min(NB3 * 16, d.Nout - f_base);                         // features of this group that exist
-      T* yblk = Y + ((int64_t)img * d.Nout + f_base) * hw_out;
-      const bool vec = (((uintptr_t)yblk) & 15) == 0 && ((nf * hw_out * SZ) & 15) == 0 && nf * hw_out * SZ <= kStageBytes;
-      if (vec) {
+      T* yblk = Y + ((int64_t)img * d.Nout + f_base) * hw_out + oy0 * d.Wo;   // first pixel of the tile, feature f_base
+      const bool fits = nf * n_out * SZ <= kStageBytes;
+      const bool vec16 = fits && d.tiles == 1 && (((uintptr_t)yblk) & 15) == 0 && ((nf * hw_out * SZ) & 15) == 0;
+      const bool vec8 = fits && !vec16 && (((uintptr_t)yblk) & 7) == 0 && ((hw_out * SZ) & 7) == 0 && ((n_out * SZ) & 7) == 0;
+      if (vec16 || vec8) {
         T* st = reinterpret_cast<T*>(reinterpret_cast<uint8_t*>(lds) + wave * kStageBytes);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -261,21 +276,29 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int fl = j * 16 + 4 * q + e;
-              if (px < hw_out && fl < nf) {
+              if (px < n_out && fl < nf) {
                 const float v = acc[mt][j][e] + (d.bias ? d.bias[f_base + fl] : 0.f);
-                if constexpr (SZ == 4) st[fl * hw_out + px] = v;
-                else st[fl * hw_out + px] = bf16_rne(v);
+                if constexpr (SZ == 4) st[fl * n_out + px] = v;
+                else st[fl * n_out + px] = bf16_rne(v);
               }
             }
         }
-        const int nvec = nf * hw_out * SZ / 16;
-        for (int i = lane; i < nvec; i += 64)
-          reinterpret_cast<uint4*>(yblk)[i] = reinterpret_cast<const uint4*>(st)[i];
+        if (vec16) {                                                           // n_out == hw_out: one contiguous block
+          const int nvec = nf * hw_out * SZ / 16;
+          for (int i = lane; i < nvec; i += 64)
+            reinterpret_cast<uint4*>(yblk)[i] = reinterpret_cast<const uint4*>(st)[i];
+        } else {
+          const int upr = n_out * SZ / 8, nunits = nf * upr;                   // 8-byte units per feature row
+          for (int i = lane; i < nunits; i += 64) {
+            const int fl = i / upr, u = i - fl * upr;
+            reinterpret_cast<uint2*>(yblk + (int64_t)fl * hw_out)[u] = reinterpret_cast<const uint2*>(st + fl * n_out)[u];
+          }
+        }
       } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int px = 16 * mt + r;
-          if (px >= hw_out) continue;
+          if (px >= n_out) continue;
 #pragma unroll
           for (int j = 0; j < NB3; ++j)
 #pragma unroll
@@ -283,7 +306,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
               const int f = f_base + j * 16 + 4 * q + e;
               if (f >= d.Nout) continue;
               const float v = acc[mt][j][e] + (d.bias ? d.bias[f] : 0.f);
-              T* p = Y + ((int64_t)img * d.Nout + f) * hw_out + px;
+              T* p = Y + ((int64_t)img * d.Nout + f) * hw_out + oy0 * d.Wo + px;
               if constexpr (SZ == 4) *p = v;
               else *p = bf16_rne(v);
             }
@@ -296,7 +319,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
 template <int P, int KC, int NBW, typename T>
 int launch_conv_nbw(const ConvChainDesc& d, hipStream_t s) {
   auto kern = tt_conv_kernel<P, KC, NBW, T>;
-  const size_t lds = ((size_t)2 * P * kCTM * (KC + kPad) + (size_t)P * kCTM * (d.R1 + kPad) + (size_t)P * kCTM * (d.R2 + kPad)) * 2;
+  const size_t lds = ((size_t)2 * P * kCTM * (KC + kPad) + (size_t)P * kCTM * d.NT * (d.R1 + kPad) + (size_t)P * kCTM * (d.R2 + kPad)) * 2;
   if (lds > 160 * 1024) return -1;
   static bool attr_done[64] = {false};
   int devi = 0;
@@ -306,7 +329,7 @@ int launch_conv_nbw(const ConvChainDesc& d, hipStream_t s) {
     (void)hipGetLastError();
     attr_done[devi & 63] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(d.B), dim3(256), lds, s, d);
+  hipLaunchKernelGGL(kern, dim3(d.B * d.tiles), dim3(256), lds, s, d);
   return 0;
 }
 

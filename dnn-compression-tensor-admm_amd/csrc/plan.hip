@@ -1315,8 +1315,15 @@ int tadmm_ttconv_fused(tadmm_handle h, const tadmm_conv_chain_desc* c, void* str
   const int ho = (c->H + 2 * c->pad_h - c->dil_h * (c->kh - 1) - 1) / c->stride_h + 1;
   const int wo = (c->W + 2 * c->pad_w - c->dil_w * (c->kw - 1) - 1) / c->stride_w + 1;
   if (ho != c->Ho || wo != c->Wo) CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: output size does not match the geometry");
-  if (c->H * c->W > 64 || ho * wo > 64 || ho <= 0 || wo <= 0)
-    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: planes of more than 64 pixels take the three-launch path");
+  if (ho <= 0 || wo <= 0 || wo > 64) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: output rows of more than 64 pixels take the three-launch path");
+  // output rows per workgroup: as many as give <= 64 output pixels and a halo of <= 192 input pixels
+  int tr = std::min(ho, 64 / wo), nt = 0;
+  for (; tr >= 1; --tr) {
+    const int irows = std::min(c->H, (tr - 1) * c->stride_h + (c->kh - 1) * c->dil_h + 1);
+    nt = (irows * c->W + 63) / 64;
+    if (nt <= 3) break;
+  }
+  if (tr < 1) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: the halo of one output row exceeds 192 pixels");
   if (c->R1 <= 0 || c->R2 <= 0 || c->R1 % 32 || c->R2 % 64 || c->R1 > 256 || c->R2 > 256)
     CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: ranks must be padded to 32 / 64 and at most 256");
   const int64_t taps = (int64_t)c->kh * c->kw;
@@ -1331,6 +1338,7 @@ int tadmm_ttconv_fused(tadmm_handle h, const tadmm_conv_chain_desc* c, void* str
   d.B = c->B; d.C = c->C; d.R1 = c->R1; d.R2 = c->R2; d.Nout = c->Nout;
   d.H = c->H; d.W = c->W; d.Ho = ho; d.Wo = wo; d.kh = c->kh; d.kw = c->kw; d.sh = c->stride_h; d.sw = c->stride_w;
   d.ph = c->pad_h; d.pw = c->pad_w; d.dh = c->dil_h; d.dw = c->dil_w;
+  d.TR = tr; d.tiles = (ho + tr - 1) / tr; d.NT = nt;
   const int epl = c->dtype == TADMM_CHAIN_F32 ? 4 : 8;
   d.x_vec = ((c->H * c->W) % epl == 0 && (((uintptr_t)c->X) & 15) == 0) ? 1 : 0;
   if (launch_tt_conv(d, c->dtype, (hipStream_t)stream_) != 0)

@@ -455,20 +455,30 @@ def chain_single(x, w_planes, bias, n_out: int, entry: str = "tadmm_ttconv_chain
 
 
 def conv_chain_fits(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation) -> bool:
-    """True when the one-launch factorised convolution (csrc/convchain.hip) applies: planes of at most 64 pixels, ranks
-    at most 256 and both intermediates inside the 160 KiB of LDS."""
+    """True when the one-launch factorised convolution (csrc/convchain.hip) applies: output rows of at most 64 pixels,
+    a tile of output rows whose halo is at most 192 input pixels, ranks at most 256 and both intermediates inside the
+    160 KiB of LDS (the same rule tadmm_ttconv_fused applies)."""
     if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
         return False
     H, W = x.shape[2], x.shape[3]
     ho = (H + 2 * padding[0] - dilation[0] * (kernel_size[0] - 1) - 1) // stride[0] + 1
     wo = (W + 2 * padding[1] - dilation[1] * (kernel_size[1] - 1) - 1) // stride[1] + 1
-    if H * W > 64 or ho * wo > 64 or ho <= 0 or wo <= 0:
+    if ho <= 0 or wo <= 0 or wo > 64:
         return False
     r1p, r2p = -(-r1 // 32) * 32, -(-r2 // 64) * 64
     if r1p > 256 or r2p > 256:
         return False
+    tr, nt = min(ho, 64 // wo), 0
+    while tr >= 1:
+        irows = min(H, (tr - 1) * stride[0] + (kernel_size[0] - 1) * dilation[0] + 1)
+        nt = -(-(irows * W) // 64)
+        if nt <= 3:
+            break
+        tr -= 1
+    if tr < 1:
+        return False
     planes, kc = (3, 64) if x.dtype == torch.float32 else (1, 128)
-    lds = (2 * planes * 64 * (kc + 8) + planes * 64 * (r1p + 8) + planes * 64 * (r2p + 8)) * 2
+    lds = (2 * planes * 64 * (kc + 8) + planes * 64 * nt * (r1p + 8) + planes * 64 * (r2p + 8)) * 2
     return lds <= 160 * 1024
 
 
@@ -484,7 +494,8 @@ def conv_core_planes(core: torch.Tensor, planes: int) -> torch.Tensor:
 
 def conv_chain(x: torch.Tensor, w1p: torch.Tensor, w2p: torch.Tensor, w3p: torch.Tensor, bias, n_out: int, kernel_size,
                stride, padding, dilation) -> torch.Tensor:
-    """y (B, n_out, Ho, Wo) = W3 conv_kxk(W1 x; Wc) + bias for small NCHW images in one launch (`tadmm_ttconv_fused`).
+    """y (B, n_out, Ho, Wo) = W3 conv_kxk(W1 x; Wc) + bias for NCHW images in one launch (`tadmm_ttconv_fused`; see
+    `conv_chain_fits` for what is eligible).
     w1p = weight_planes(W1, P, pad_rows=32), w2p = conv_core_planes(core, P), w3p = weight_planes(W3, P, pad_cols=64)."""
     if not x.is_cuda:
         raise TadmmError(-1, "x must live on a HIP device; there is no CPU path")

@@ -241,7 +241,8 @@ int tadmm_ttconv_chain_out(tadmm_handle h, const tadmm_chain_desc* d, void* stre
 int tadmm_tucker_1x1(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
 
 /* The whole factorised convolution of a SMALL image in one launch (csrc/convchain.hip): y = W3 conv_kxk(W1 x; Wc) + bias
- * for NCHW tensors whose input and output planes have at most 64 pixels; the two intermediates stay in LDS.  TTConv2dM
+ * for NCHW tensors with output rows of at most 64 pixels: one workgroup per tile of output rows (<= 64 output pixels, a halo of
+ * <= 192 input pixels); the two intermediates stay in LDS.  TTConv2dM
  * (TTConv.py:130-153), TKConv2dC / TKConv2dM (TKConv.py:93-98, :210-214).  W1 (R1 x C), W2 (R2 x kh*kw*R1, tap-major:
  * column (dy*kw + dx)*R1 + c) and W3 (Nout x R2) are fragment-major bf16 planes as for tadmm_chain_desc, R1 a multiple of
  * 32 and R2 of 64 (zero padded), both <= 256; groups = 1.  Returns TADMM_ERR_UNSUPPORTED when the image or the

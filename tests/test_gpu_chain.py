@@ -183,6 +183,11 @@ def test_ttlinearm_fused_backward_matches_fp64_autograd():
     (2, 48, 6, 6, 24, 24, 40, 5, 1, 2, 1),       # 5x5 taps
     (2, 32, 7, 7, 12, 12, 16, 3, 1, 2, 2),       # dilation 2
     (4, 40, 5, 5, 9, 11, 12, 1, 1, 0, 1),        # 1x1 core
+    (3, 64, 14, 14, 40, 36, 48, 3, 1, 1, 1),     # 14x14: four output rows per workgroup, halo of six input rows
+    (2, 32, 28, 28, 24, 24, 40, 3, 1, 1, 1),     # 28x28: two output rows per workgroup
+    (2, 16, 56, 56, 12, 16, 24, 3, 1, 1, 1),     # 56x56: one output row per workgroup, 3 x 56 pixels of halo
+    (2, 48, 14, 14, 20, 20, 32, 3, 2, 1, 1),     # stride 2: 14x14 -> 7x7 in one tile, halo = the whole input plane (196 px: NT > 3 -> smaller tile)
+    (2, 24, 20, 12, 16, 16, 24, 5, 1, 2, 1),     # non-square plane, 5x5 taps
 ])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_chain_matches_three_torch_convs(B, C, H, W, r1, r2, O, k, stride, pad, dil, dtype):
@@ -211,8 +216,8 @@ def test_conv_chain_matches_three_torch_convs(B, C, H, W, r1, r2, O, k, stride, 
 
 
 def test_small_image_conv_layers_take_the_fused_launch(monkeypatch):
-    """TTConv2dM / TKConv2dC / TKConv2dM in inference on planes of <= 64 pixels: one `tadmm_ttconv_fused` launch, equal to
-    the three-launch path (the path training and larger images take)."""
+    """TTConv2dM / TKConv2dC / TKConv2dM in inference: one `tadmm_ttconv_fused` launch (whole plane or row tiles), equal to
+    the three-launch path (the path training and very wide planes take)."""
     from tadmm import ops, tk_layers, tt_layers
     torch.manual_seed(3)
     hp = _HP()
@@ -237,7 +242,13 @@ def test_small_image_conv_layers_take_the_fused_launch(monkeypatch):
         y3 = layer(x)                                        # grad mode: three launches, differentiable
         assert len(calls) == n0 + 1 and y3.requires_grad
         assert (y - y3.detach()).abs().max().item() < 5e-6 * y3.abs().max().item()
-        big = torch.randn(2, 64, 14, 14, device="cuda")      # 196 pixels: not eligible
+        big = torch.randn(2, 64, 14, 14, device="cuda")      # 196 pixels: row tiles, still one launch
         with torch.no_grad():
-            layer(big)
-        assert len(calls) == n0 + 1
+            yb = layer(big)
+        assert len(calls) == n0 + 2
+        yb3 = layer(big)
+        assert (yb - yb3.detach()).abs().max().item() < 5e-6 * yb3.abs().max().item()
+        wide = torch.randn(1, 64, 4, 80, device="cuda")      # rows of 80 pixels: three launches
+        with torch.no_grad():
+            layer(wide)
+        assert len(calls) == n0 + 2

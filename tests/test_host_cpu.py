@@ -239,7 +239,8 @@ def test_eigen_problem_size_limit_is_reported_not_hidden():
 
 def test_chain_eligibility_rules_are_pure_host_logic():
     """Which forward path a layer takes is decided on the host from shapes alone (no GPU needed): the fused conv launch
-    for planes of <= 64 pixels whose intermediates fit the LDS, the fused linear chain for middle ranks <= 256."""
+    for output rows of <= 64 pixels whose halo and intermediates fit the LDS, the fused linear chain for middle ranks
+    <= 256."""
     import torch
     from tadmm import functional as HF
     from tadmm import ops
@@ -247,7 +248,9 @@ def test_chain_eligibility_rules_are_pure_host_logic():
     assert ops.conv_chain_fits(x, 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))
     assert ops.conv_chain_fits(x.to(torch.bfloat16), 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))
     assert not ops.conv_chain_fits(x, 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))          # three planes of 224: > 160 KiB
-    assert not ops.conv_chain_fits(torch.zeros(2, 64, 14, 14), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))   # 196 pixels
+    assert ops.conv_chain_fits(torch.zeros(2, 64, 14, 14), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))       # row tiles
+    assert not ops.conv_chain_fits(torch.zeros(2, 8, 112, 112), 8, 8, (3, 3), (1, 1), (1, 1), (1, 1))    # rows of 112 pixels
+    assert not ops.conv_chain_fits(torch.zeros(2, 8, 56, 56), 8, 8, (7, 7), (1, 1), (3, 3), (1, 1))      # halo of 7 rows > 192 px
     assert not ops.conv_chain_fits(x, 300, 25, (3, 3), (1, 1), (1, 1), (1, 1))           # rank > 256
     assert not ops.conv_chain_fits(x.double(), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))
     assert ops.conv_chain_fits(x, 23, 25, (3, 3), (2, 2), (1, 1), (1, 1))                 # stride 2: 8x8 -> 4x4
