@@ -238,43 +238,69 @@ void launch_chol_factor(const CholDesc* descs_dev, int nprob, hipStream_t s) {
 
 __global__ __launch_bounds__(256) void chol_solve_kernel(const CholDesc* __restrict__ descs,
                                                          const BlockRef* __restrict__ map) {
+  // R's column block kb (tiles (j, kb), j < kb: the A operands of step kb) is the same for every wave of the problem.
+  // Read straight from global memory by each MFMA it costs a wave 512 bytes per 64-cycle MFMA -- four waves saturate
+  // what a CU gets from L2 -- so the workgroup stages it ONCE in LDS (double-buffered, fetched one step ahead).
+  __shared__ double Rs[2][(kCMaxT - 1) * kCT * kCT];
   const BlockRef br = map[blockIdx.x];
   const CholDesc d = descs[br.prob];
   if (d.gate && *d.gate < d.gate_min) return;
   if (*d.bad) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int nbt = d.n / kCT;
   int ring = d.rot ? *d.rot + d.sel : d.sel;
   ring -= (ring >= 3) ? 3 : 0;
   ring -= (ring >= 3) ? 3 : 0;
-  if (d.rot_out && br.local == 0 && threadIdx.x == 0) *d.rot_out = ring;
-  double* __restrict__ Y = ring == 0 ? d.ring[0] : (ring == 1 ? d.ring[1] : d.ring[2]);
-  if (br.local * 64 + wave * 16 >= d.ncols) return;      // ncols is a multiple of 16: whole waves drop out
-  const int col = br.local * 64 + wave * 16 + r;
-  const int64_t ldy = d.ldy;
+  if (d.rot_out && br.local == 0 && tid == 0) *d.rot_out = ring;
+  G<double>* __restrict__ Y = gp(ring == 0 ? d.ring[0] : (ring == 1 ? d.ring[1] : d.ring[2]));
+  const G<const double>* __restrict__ R = gp((const double*)d.R);
+  const G<const double>* __restrict__ Wd = gp((const double*)d.Wd);
+  const bool active = br.local * 64 + wave * 16 < d.ncols;   // ncols is a multiple of 16: whole waves idle, but they
+  const int col = br.local * 64 + wave * 16 + r;             // still help staging R and keep the barriers
+  const int64_t ldy = d.ldy, ldr = d.ldr;
+  // element t + 256 i of column block kb: tile j = i (256 doubles per tile), row kk = t / 16, column m = t % 16
+  const int srow = tid >> 4, scol = tid & 15;
+  double pre[kCMaxT - 1];
+  auto fetch = [&](int kb) {                                  // tiles (j, kb), j < kb -> registers
+#pragma unroll
+    for (int j = 0; j < kCMaxT - 1; ++j)
+      if (j < kb && kb < nbt) pre[j] = R[(int64_t)(kCT * j + srow) * ldr + kCT * kb + scol];
+  };
+  auto stash = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < kCMaxT - 1; ++j)
+      if (j < kb) Rs[kb & 1][j * (kCT * kCT) + tid] = pre[j];
+  };
   double4_t X[kCMaxT];
+  fetch(1);
 #pragma unroll
   for (int kb = 0; kb < kCMaxT; ++kb) {
     if (kb < nbt) {
-      double4_t acc;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col];
-#pragma unroll
-      for (int j = 0; j < kb; ++j) {
-        // A[m][kk] = R[16j + kk][16kb + m], kk = q + 4e (the k order of the D-layout B operand X[j])
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-d.R[(int64_t)(kCT * j + q + 4 * e) * d.ldr + kCT * kb + r], X[j][e],
-                                                     acc, 0, 0, 0);
+      if (kb >= 1) {
+        stash(kb);
+        __syncthreads();
       }
-      double4_t o = {0, 0, 0, 0};
-      const double* W = d.Wd + (int64_t)kb * (kCT * kCT);
+      fetch(kb + 1);
+      if (active) {
+        double4_t acc;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f64_16x16x4f64(W[r * kCT + q + 4 * e], acc[e], o, 0, 0, 0);
-      X[kb] = o;
+        for (int e = 0; e < 4; ++e) acc[e] = Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col] = o[e];
+        for (int j = 0; j < kb; ++j) {
+          // A[m][kk] = R[16j + kk][16kb + m], kk = q + 4e (the k order of the D-layout B operand X[j])
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Rs[kb & 1][j * (kCT * kCT) + (q + 4 * e) * kCT + r], X[j][e], acc, 0, 0, 0);
+        }
+        double4_t o = {0, 0, 0, 0};
+        const G<const double>* W = Wd + (int64_t)kb * (kCT * kCT);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f64_16x16x4f64(W[r * kCT + q + 4 * e], acc[e], o, 0, 0, 0);
+        X[kb] = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col] = o[e];
+      }
     }
   }
 }
