@@ -201,11 +201,16 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
   int did = 0;
   if (!kMeasure || mx > 1e-15) {
     const int g8 = lane >> 3, l8 = lane & 7;
-    const double scale2 = inv_hmax;                       // entries of H_cur are ~lambda^2 <= hmax
     // rotation of rows (p,q) given the three entries a = h_pp, b = h_qq, g = h_pq of the current matrix
     auto rotation = [&](double a, double b, double g, double& c, double& s, double& t) -> bool {
       if (!(g * g > 1e-36 * fabs(a * b) && fabs(g) > 1e-300)) return false;   // uniform inside the 8-lane group
-      const float zf = (float)((b - a) * scale2), wf = (float)(2.0 * g * scale2);
+      // (b - a) and 2g are brought to a common binary exponent before they are narrowed to fp32: at the rounding floor of a
+      // rank-deficient block (columns annihilated to ~1e-16 of the others, entries ~1e-32 hmax) both used to underflow to
+      // zero in fp32 and the angle became 0 * inf = NaN -- eight (nearly) identical columns in one block were enough
+      const double zd = b - a, wd = 2.0 * g;
+      const int ew = __builtin_amdgcn_frexp_exp(wd);
+      const int ex = zd == 0.0 ? ew : max(__builtin_amdgcn_frexp_exp(zd), ew);
+      const float zf = (float)__builtin_amdgcn_ldexp(zd, -ex), wf = (float)__builtin_amdgcn_ldexp(wd, -ex);
       const float az = fabsf(zf), aw = fabsf(wf);
       float tf;
       if (az >= aw) {

@@ -200,3 +200,48 @@ def test_fp32_accuracy_filter_stages_are_opt_in_and_verified(dev, monkeypatch):
     for a, b in zip(z_fast, z_ref):
         rel = ((a.double() - b.double()).norm() / b.double().norm()).item()
         assert rel < 1e-6, rel
+
+
+@pytest.mark.parametrize("N", [16, 128, 480, 1152])
+def test_eigh_of_blocks_of_identical_columns(dev, N):
+    """Eight or more (nearly) identical columns in one Jacobi block: after the first annihilations the block works at its
+    rounding floor (entries ~1e-32 of the largest), where the fp32 narrowing of the rotation angle used to underflow to
+    0 * inf = NaN -- a constant weight tensor was enough to lose the dominant eigenvalue silently (N >= 192) or to end in
+    TADMM_ERR_NOCONVERGE (small N).  The operands of the angle are now brought to a common exponent first."""
+    from tadmm import ops
+    g0 = torch.Generator().manual_seed(N)
+    cases = {"ones": torch.ones(N, N, dtype=torch.float64)}
+    blk = torch.zeros(N, N, dtype=torch.float64); blk[:8, :8] = 1.0
+    cases["8x8 block"] = blk
+    st = torch.zeros(N, N, dtype=torch.float64); st[4:12, 4:12] = 1.0; st[4, 4] += 1e-13
+    cases["straddling, jittered"] = st
+    v = torch.randn(N, 3, generator=g0, dtype=torch.float64)
+    cases["rank 3"] = v @ v.t()
+    for name, G in cases.items():
+        lam, V, sweeps = ops.eigh(G.to(dev))
+        ref = torch.linalg.eigvalsh(G).flip(0)
+        assert torch.isfinite(lam).all() and torch.isfinite(V).all(), name
+        assert (lam.cpu() - ref).abs().max().item() <= 1e-12 * ref.abs().max().item(), name
+        assert sweeps <= 12, (name, sweeps)
+
+
+def test_constant_weight_tensor_projects_like_the_oracle(dev):
+    """A layer whose weights are all equal (rank-1 unfoldings, identical Gram columns) beside ordinary layers."""
+    from tadmm import ops
+    from tadmm._cabi import KIND_TT_CONV
+    g0 = torch.Generator().manual_seed(2)
+    shapes = [4, 4, 9, 4, 4]
+    ranks = [1, 4, 12, 12, 4, 1]
+    ws = [torch.full((16, 16, 3, 3), 0.37), torch.randn(16, 16, 3, 3, generator=g0) * 0.1,
+          torch.full((16, 16, 3, 3), -2.5e-3), torch.randn(16, 16, 3, 3, generator=g0) * 0.1]
+    ls = [dict(kind=KIND_TT_CONV, W=w.to(dev).contiguous(), U=torch.zeros_like(w).to(dev), Z=torch.zeros_like(w).to(dev),
+               tt_shapes=list(shapes), ranks=list(ranks)) for w in ws]
+    pl = ops.ProjectionPlan(ls)
+    pl.run(update_u=False)
+    torch.cuda.synchronize()
+    for w, L in zip(ws, ls):
+        z = O.prune_conv_rank_tt(w.numpy(), list(shapes), list(ranks))
+        got = L["Z"].cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.linalg.norm(got - z) <= 1e-5 * np.linalg.norm(z)
+    pl.close()
