@@ -82,19 +82,20 @@ def run(device=None, iters: int = 50):
                 r["contracted_flops_per_token"] = int(2 * rq * (fin + fout))
                 r["dense_flops_per_token"] = int(2 * fin * fout)
                 rows.append(r)
-        # ---- TTConv2dM: ResNet-18 layer4.0.conv2 (512, 512, 3, 3), x (64, 512, 7, 7)
+        # ---- TTConv2dM: ResNet-18 layer3.1.conv1 (256, 256, 3, 3) at 14x14 and layer4.0.conv2 (512, 512, 3, 3) at 7x7, B = 64
         hp18 = HPM.fresh_table("tt_resnet18_hp.HyperParamsDictGeneralRatio2x")
-        conv = tt_layers.TTConv2dM(512, 512, 3, padding=1, bias=False, hp_dict=hp18, name="layer4.0.conv2.weight").to(dev)
-        wc = torch.randn(512, 512, 3, 3, generator=g).to(dev)
-        for dtype in (torch.float32, torch.bfloat16):
-            xc = torch.randn(64, 512, 7, 7, generator=g).to(dev).to(dtype)
-            wcd = wc.to(dtype)
-            ms = _time(lambda: conv(xc), iters)
-            dense = _time(lambda: F.conv2d(xc, wcd, None, 1, 1), iters)
-            one = ops.conv_chain_fits(xc, conv.in_tt_ranks[0], conv.out_tt_ranks[-1], conv.kernel_size, conv.stride,
-                                      conv.padding, conv.dilation)
-            rows.append(_row("TTConv2dM resnet18 layer4.0.conv2 (B=64, 7x7, ranks %s)" % conv.tt_ranks, dtype, ms, dense,
-                             None, 0.0, 1 if one else 3))
+        for lname, ch, hw in (("layer3.1.conv1.weight", 256, 14), ("layer4.0.conv2.weight", 512, 7)):
+            conv = tt_layers.TTConv2dM(ch, ch, 3, padding=1, bias=False, hp_dict=hp18, name=lname).to(dev)
+            wc = torch.randn(ch, ch, 3, 3, generator=g).to(dev)
+            for dtype in (torch.float32, torch.bfloat16):
+                xc = torch.randn(64, ch, hw, hw, generator=g).to(dev).to(dtype)
+                wcd = wc.to(dtype)
+                ms = _time(lambda: conv(xc), iters)
+                dense = _time(lambda: F.conv2d(xc, wcd, None, 1, 1), iters)
+                one = ops.conv_chain_fits(xc, conv.in_tt_ranks[0], conv.out_tt_ranks[-1], conv.kernel_size, conv.stride,
+                                          conv.padding, conv.dilation)
+                rows.append(_row("TTConv2dM resnet18 %s (B=64, %dx%d, ranks %s)" % (lname[:-7], hw, hw, conv.tt_ranks), dtype,
+                                 ms, dense, None, 0.0, 1 if one else 3))
         # ---- TKConv2dC: ResNet-32 layer3 3x3 (64, 64, 3, 3), x (128, 64, 8, 8)
         hp32 = HPM.fresh_table("tk_resnet32_hp.HyperParamsDictRatio3x")
         tk = tk_layers.TKConv2dC(64, 64, 3, padding=1, bias=False, hp_dict=hp32, name="layer3.1.conv1.weight").to(dev)
