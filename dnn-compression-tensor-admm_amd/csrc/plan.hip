@@ -765,7 +765,17 @@ static bool lane_split(tadmm_handle h, int n, const tadmm_layer_desc* descs, std
     lane_of[l] = lat[l] >= thr * lmax ? 0 : 1;
     if (lane_of[l] == 0) ++n0; else t1 += lat[l];
   }
-  if (n0 == 0 || n - n0 < 2 || t1 < 0.2 * lmax) { lane_of.assign(n, 0); return false; }
+  if (n0 == 0 || n - n0 < 2 || t1 < 0.2 * lmax) {
+    // no short side to hide behind the long chains.  A big table of like layers (DeiT-small: 48 layers, every chain
+    // within 0.6 of the longest) still gains from two half tables on two streams -- one lane's GEMM phases fill the gaps
+    // of the other's eigen-solves (12.3 -> 10.9 ms); small or short tables stay in one lane.
+    if (n >= 16 && n0 >= n - 1 && lmax >= 2000.0) {
+      for (int l = 0; l < n; ++l) lane_of[l] = l < n / 2 ? 0 : 1;
+      return true;
+    }
+    lane_of.assign(n, 0);
+    return false;
+  }
   return true;
 }
 

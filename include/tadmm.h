@@ -137,7 +137,8 @@ int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
  * short ones runs as two sub-plans on two device streams -- the long chains on a high-priority stream, the rest
  * filling the CUs they leave idle; the caller's stream is joined in front and behind, the second lane is driven by a
  * worker thread owned by the plan.  Returns the number of lanes (1 or 2) and, when lane_of_out is not NULL, each
- * layer's lane.  TADMM_LANES=1 in the environment keeps every plan in one lane; TADMM_LANE_THRESHOLD (default 0.6)
+ * layer's lane.  A big table of like layers (>= 16, every chain within the threshold of the longest) is split into two halves.
+ * TADMM_LANES=1 in the environment keeps every plan in one lane; TADMM_LANE_THRESHOLD (default 0.6)
  * is the fraction of the longest modelled chain from which a layer counts as long. */
 int tadmm_plan_lanes(tadmm_plan p, int32_t* lane_of_out);
 int tadmm_plan_destroy(tadmm_plan p);
