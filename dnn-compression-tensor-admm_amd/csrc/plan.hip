@@ -936,6 +936,14 @@ static void lanes_destroy(tadmm_plan_s* p) {
   p->lanes = nullptr;
 }
 
+int tadmm_lane_split(int n_layers, const tadmm_layer_desc* descs, int32_t* lane_of_out) {
+  if (!descs || n_layers <= 0) return TADMM_ERR_INVALID;
+  std::vector<int> lane_of;
+  const bool two = lane_split(nullptr, n_layers, descs, lane_of);
+  if (lane_of_out) for (int l = 0; l < n_layers; ++l) lane_of_out[l] = lane_of[l];
+  return two ? 2 : 1;
+}
+
 int tadmm_plan_lanes(tadmm_plan p, int32_t* lane_of_out) {
   if (!p) return TADMM_ERR_INVALID;
   if (!p->lanes) { if (lane_of_out) for (int l = 0; l < p->n; ++l) lane_of_out[l] = 0; return 1; }

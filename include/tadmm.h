@@ -141,6 +141,8 @@ int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
  * TADMM_LANES=1 in the environment keeps every plan in one lane; TADMM_LANE_THRESHOLD (default 0.6)
  * is the fraction of the longest modelled chain from which a layer counts as long. */
 int tadmm_plan_lanes(tadmm_plan p, int32_t* lane_of_out);
+/* The split rule alone (pure host function of the descriptors, no device needed): what tadmm_plan_create would do. */
+int tadmm_lane_split(int n_layers, const tadmm_layer_desc* descs, int32_t* lane_of_out);
 int tadmm_plan_destroy(tadmm_plan p);
 
 /* ---- Tucker-2 projection plan (admm.py:113-127: tensorly partial_tucker + tucker_to_tensor) ---- */

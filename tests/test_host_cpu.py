@@ -256,3 +256,38 @@ def test_chain_eligibility_rules_are_pure_host_logic():
     assert ops.conv_chain_fits(x, 23, 25, (3, 3), (2, 2), (1, 1), (1, 1))                 # stride 2: 8x8 -> 4x4
     assert not ops.conv_chain_fits(x, 23, 25, (9, 9), (1, 1), (0, 0), (1, 1))             # empty output plane
     assert HF.fused_rank_ok(256) and not HF.fused_rank_ok(257) and not HF.fused_rank_ok(0)
+
+
+def test_lane_split_rule_on_the_benchmark_tables():
+    """tadmm_lane_split is a pure host function of the layer descriptors (what tadmm_plan_create does): ResNet-50 puts the
+    nine 3x3 kernels of layer3 / layer4 on the priority lane, DeiT-small (48 like layers) is halved, small tables and
+    TADMM_LANES=1 stay in one lane."""
+    import ctypes as C
+    from tadmm import _cabi, workloads
+    from tadmm._cabi import FLAG_SKIP_ROTATIONS, KIND_TT_CONV, KIND_TT_LINEAR
+    lib = _cabi.load()
+
+    def split(cfg, take=None):
+        m, hp, _ = workloads.build(cfg)
+        items = [(n, p) for n, p in m.named_parameters()][:take]
+        descs = (_cabi.LayerDesc * len(items))()
+        for i, (n, p) in enumerate(items):
+            kind = KIND_TT_CONV if p.dim() == 4 else KIND_TT_LINEAR
+            descs[i] = _cabi.make_layer_desc(kind, list(p.shape), hp.tt_shapes[n], list(hp.ranks[n]), FLAG_SKIP_ROTATIONS)
+        out = (C.c_int32 * len(items))()
+        lanes = lib.tadmm_lane_split(len(items), descs, out)
+        return lanes, [n for n, _ in items], list(out)
+
+    lanes, names, lane_of = split("resnet50_tt")
+    assert lanes == 2
+    long_chain = [n for n, l in zip(names, lane_of) if l == 0]
+    assert len(long_chain) == 9 and all(".conv2." in n and n[:6] in ("layer3", "layer4") for n in long_chain)
+    lanes, names, lane_of = split("deit_small_tt")
+    assert lanes == 2 and lane_of == [0] * 24 + [1] * 24
+    lanes, _, lane_of = split("resnet50_tt", take=3)
+    assert lanes == 1 and set(lane_of) == {0}
+    os.environ["TADMM_LANES"] = "1"
+    try:
+        assert split("resnet50_tt")[0] == 1
+    finally:
+        del os.environ["TADMM_LANES"]
