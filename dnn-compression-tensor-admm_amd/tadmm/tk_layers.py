@@ -285,6 +285,27 @@ class _TKLinearBase(nn.Module):
 
 class TKLinearM(_TKLinearBase):
     def forward(self, x: Tensor) -> Tensor:                       # TKLinear.py:66-71
+        """Three products in the reference; here the small core is contracted into the input factor and the layer is one
+        launch of the fused chain (`tadmm_ttlinear_fwd`: y = last (core first) x + bias, the out_rank-vector of a token in
+        LDS) whenever out_rank fits it; otherwise three strided GEMMs."""
+        align = 8 if x.dtype == torch.bfloat16 else 4
+        if (x.dtype in (torch.float32, torch.bfloat16) and HF.fused_rank_ok(self.out_rank) and x.is_cuda
+                and self.in_features % align == 0):
+            params = (self.first_factor, self.core_tensor, self.last_factor)
+            grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            if grad and x.dtype == torch.float32:
+                w_in = HF.mm(self.core_tensor, self.first_factor)             # (out_rank, in_features), differentiable
+                return HF.linear_chain(x, w_in, self.last_factor, self.bias)
+            if not grad:
+                n = 1 if x.dtype == torch.bfloat16 else 3
+                cache = self.__dict__.setdefault("_chain_cache", {})
+                key = (n, x.device, tuple(p._version for p in params))
+                if cache.get("key") != key:
+                    with torch.no_grad():
+                        w_in = HF.mm(self.core_tensor, self.first_factor)
+                    cache.update(key=key, w_in=w_in, planes=(HF.planes_of(w_in, n, pad_rows=64),
+                                                             HF.planes_of(self.last_factor, n, pad_cols=64)))
+                return HF.linear_chain(x, cache["w_in"], self.last_factor, self.bias, cache["planes"])
         out = HF.linear(x, self.first_factor)
         out = HF.linear(out, self.core_tensor)
         return HF.linear(out, self.last_factor, self.bias)

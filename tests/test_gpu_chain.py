@@ -252,3 +252,34 @@ def test_small_image_conv_layers_take_the_fused_launch(monkeypatch):
         with torch.no_grad():
             layer(wide)
         assert len(calls) == n0 + 2
+
+
+def test_tklinearm_runs_on_the_fused_chain_and_is_differentiable(monkeypatch):
+    from tadmm import ops, tk_layers
+    torch.manual_seed(5)
+    hk = _HP()
+    hk.ranks = {"k.weight": [40, 24]}
+    lin = tk_layers.TKLinearM(96, 128, bias=True, hp_dict=hk, name="k.weight").cuda()
+    with torch.no_grad():
+        lin.bias.normal_()
+    x = torch.randn(333, 96, device="cuda")
+    calls = []
+    real = ops.chain_fused
+    monkeypatch.setattr(ops, "chain_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        y = lin(x)
+    assert len(calls) == 1
+    W = (lin.last_factor.double() @ lin.core_tensor.double() @ lin.first_factor.double())
+    ref = x.double() @ W.t() + lin.bias.double()
+    assert (y.double() - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
+    xg = x.clone().requires_grad_(True)
+    yg = lin(xg)
+    gy = torch.randn_like(yg)
+    yg.backward(gy)
+    params = [p.detach().double().requires_grad_(True) for p in (lin.first_factor, lin.core_tensor, lin.last_factor, lin.bias)]
+    xd = x.double().requires_grad_(True)
+    yd = xd @ (params[2] @ params[1] @ params[0]).t() + params[3]
+    yd.backward(gy.double())
+    assert (xg.grad.double() - xd.grad).abs().max().item() < 1e-5 * xd.grad.abs().max().item()
+    for p, pd in zip((lin.first_factor, lin.core_tensor, lin.last_factor, lin.bias), params):
+        assert (p.grad.double() - pd.grad).abs().max().item() < 2e-5 * pd.grad.abs().max().item()
