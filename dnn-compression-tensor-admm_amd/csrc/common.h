@@ -157,9 +157,9 @@ struct ConvChainDesc {
   const uint16_t* W1; const uint16_t* W2; const uint16_t* W3;   // fragment-major bf16 planes
   const float* bias;
   int64_t w1_plane, w2_plane, w3_plane;
-  int32_t B, C, R1, R2, Nout;                                   // R1 % 32 == 0, R2 % 64 == 0 (zero padded), <= 256
+  int32_t B, C, R1, R2, Nout;                                   // R1, R2 multiples of 32 (zero padded), <= 256
   int32_t H, W, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
-  int32_t TR, tiles, NT;                                        // output rows per workgroup, tiles per image, 64-pixel tiles of its halo
+  int32_t TM, TR, tiles, NT;                                    // pixels per workgroup (64 | 32), its output rows, tiles per image, TM-pixel tiles of its halo
   int32_t x_vec;
 };
 int launch_tt_conv(const ConvChainDesc& d, int dtype, hipStream_t s);

@@ -19,7 +19,6 @@
 namespace tadmm {
 namespace {
 
-constexpr int kCTM = 64;                     // pixels per workgroup = whole image
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // gathered token fragments of one k-step: row src[mt] of the LDS image (or zeros), three or one plane
@@ -49,11 +48,11 @@ __device__ __forceinline__ void mma_tile(const bf16x8_t (&a)[P], const bf16x8_t 
 }
 
 // acc (features 4q..4q+3 of token row0 + r, tile j) -> P planes of an LDS image [P][prow][ld]
-template <int P, int NB>
-__device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[kCTM / 16][NB], uint16_t* img, int prow, int row0, int ld,
+template <int P, int TM, int NB>
+__device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[TM / 16][NB], uint16_t* img, int prow, int row0, int ld,
                                            int f_base, int nfeat, int r, int q) {
 #pragma unroll
-  for (int mt = 0; mt < kCTM / 16; ++mt)
+  for (int mt = 0; mt < TM / 16; ++mt)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int f0 = f_base + 16 * j + 4 * q;
@@ -70,14 +69,14 @@ __device__ __forceinline__ void acc_to_lds(const float4v_t (&acc)[kCTM / 16][NB]
 // Chunk of the image's input plane into the registers of a ChunkLoader (image layout): the workgroup's 64 token rows
 // are the pixels of ONE image, so element (pixel, channel) sits at X + (img*C + c)*hw + pixel -- no division per element
 // as in the general image loader, which matters for planes whose size is not a multiple of the vector width (7x7).
-template <int P, int KC, typename T>
-__device__ __forceinline__ void conv_load(ChunkLoader<P, kCTM, KC, T, true>& ld, const T* X, int img, int C, int hw,
+template <int P, int TM, int KC, typename T>
+__device__ __forceinline__ void conv_load(ChunkLoader<P, TM, KC, T, true>& ld, const T* X, int img, int C, int hw,
                                           int p_off, int k0, bool vec, int tid) {
   constexpr int EPL = 16 / sizeof(T);
 #pragma unroll
-  for (int i = 0; i < ChunkLoader<P, kCTM, KC, T, true>::NV; ++i) {
+  for (int i = 0; i < ChunkLoader<P, TM, KC, T, true>::NV; ++i) {
     const int v = tid + 256 * i;
-    const int c = k0 + v / (kCTM / EPL), p0 = p_off + (v % (kCTM / EPL)) * EPL;     // p0: pixel of the plane
+    const int c = k0 + v / (TM / EPL), p0 = p_off + (v % (TM / EPL)) * EPL;     // p0: pixel of the plane
     const T* base = X + ((int64_t)img * C + min(c, C - 1)) * hw;
     uint4 r = make_uint4(0, 0, 0, 0);
     if (vec) {
@@ -92,12 +91,13 @@ __device__ __forceinline__ void conv_load(ChunkLoader<P, kCTM, KC, T, true>& ld,
   }
 }
 
+// TM: pixels per workgroup (64, or 32 when three planes of a TT-rank intermediate would not fit the LDS otherwise).
 // NBW: feature tiles (16 wide) per wave in products 1 and 2 (4 * NBW * 16 >= max(R1, R2)) and per pass in product 3
-template <int P, int KC, int NBW, typename T>
+template <int P, int TM, int KC, int NBW, typename T>
 __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-  constexpr int MT = kCTM / 16, LDX = KC + kPad, SPC = KC / 32;
-  constexpr int kStageBytes = 2 * P * kCTM * LDX * 2 / 4;    // per wave: a quarter of the chunk buffers (free after product 1)
+  constexpr int MT = TM / 16, LDX = KC + kPad, SPC = KC / 32;
+  constexpr int kStageBytes = 2 * P * TM * LDX * 2 / 4;    // per wave: a quarter of the chunk buffers (free after product 1)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
   const int oy0 = tile * d.TR, orows = min(d.TR, d.Ho - oy0), n_out = orows * d.Wo;
   const int iy_lo = max(0, oy0 * d.sh - d.ph), iy_hi = min(d.H - 1, (oy0 + orows - 1) * d.sh - d.ph + (d.kh - 1) * d.dh);
   const int n_in = max(0, iy_hi - iy_lo + 1) * d.W, p_in0 = iy_lo * d.W;
-  const int ntt = (n_in + kCTM - 1) / kCTM;                    // token tiles of product 1 (<= d.NT)
-  const int prow1 = kCTM * d.NT;
+  const int ntt = (n_in + TM - 1) / TM;                    // token tiles of product 1 (<= d.NT)
+  const int prow1 = TM * d.NT;
   uint16_t* Xs = lds;                                          // [2][P][64][LDX]
   const int ld1 = d.R1 + kPad, ld2 = d.R2 + kPad;
-  uint16_t* H1s = lds + 2 * P * kCTM * LDX;                    // [P][64 * NT][ld1]
+  uint16_t* H1s = lds + 2 * P * TM * LDX;                    // [P][64 * NT][ld1]
   uint16_t* H2s = H1s + P * prow1 * ld1;                       // [P][64][ld2]
 
   // ---------------- product 1: H1 = X W1^T over the halo's input pixels, 64 at a time (chain.hip, product 1)
@@ -127,25 +127,25 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
     const int nchunks = (d.C + KC - 1) / KC;
     const T* X = static_cast<const T*>(d.X);
     for (int tt = 0; tt < ntt; ++tt) {
-      const int p_off = p_in0 + kCTM * tt;                     // first plane pixel of this token tile
+      const int p_off = p_in0 + TM * tt;                     // first plane pixel of this token tile
       const bool xvec = d.x_vec != 0 && (p_off % (16 / (int)sizeof(T))) == 0;
       float4v_t acc[MT][NBW];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NBW; ++j) acc[mt][j] = float4v_t{0.f, 0.f, 0.f, 0.f};
-      ChunkLoader<P, kCTM, KC, T, true> ld;
+      ChunkLoader<P, TM, KC, T, true> ld;
       // weight fragments RD1 k-steps ahead (ring indexed statically: RD1 divides the k-steps of a chunk)
       constexpr int RD1 = (SPC % 4 == 0) ? 4 : 2;
       bf16x8_t b[RD1][P][NBW];
-      conv_load<P, KC, T>(ld, X, img, d.C, hw_in, p_off, 0, xvec, tid);
+      conv_load<P, TM, KC, T>(ld, X, img, d.C, hw_in, p_off, 0, xvec, tid);
 #pragma unroll
       for (int u = 0; u < RD1 - 1; ++u) load_w<P, NBW>(b[u], w1, d.w1_plane, min(u, KS1 - 1));
       ld.store(Xs, tid);
       __syncthreads();
       for (int c = 0; c < nchunks; ++c) {
-        const uint16_t* Xc = Xs + (c & 1) * (P * kCTM * LDX);
-        conv_load<P, KC, T>(ld, X, img, d.C, hw_in, p_off, min(c + 1, nchunks - 1) * KC, xvec, tid);
+        const uint16_t* Xc = Xs + (c & 1) * (P * TM * LDX);
+        conv_load<P, TM, KC, T>(ld, X, img, d.C, hw_in, p_off, min(c + 1, nchunks - 1) * KC, xvec, tid);
 #pragma unroll
         for (int ks = 0; ks < SPC; ++ks) {
           load_w<P, NBW>(b[(ks + RD1 - 1) % RD1], w1, d.w1_plane, min(c * SPC + ks + RD1 - 1, KS1 - 1));
@@ -154,15 +154,15 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
             bf16x8_t a[P];
 #pragma unroll
             for (int p = 0; p < P; ++p)
-              a[p] = *reinterpret_cast<const bf16x8_t*>(&Xc[(p * kCTM + 16 * mt + r) * LDX + 32 * ks + 8 * q]);
+              a[p] = *reinterpret_cast<const bf16x8_t*>(&Xc[(p * TM + 16 * mt + r) * LDX + 32 * ks + 8 * q]);
             mma_tile<P, NBW>(a, b[ks % RD1], acc[mt]);
           }
         }
         static_assert(SPC % RD1 == 0, "fragment ring returns to slot 0 at every chunk boundary");
-        ld.store(Xs + ((c + 1) & 1) * (P * kCTM * LDX), tid);
+        ld.store(Xs + ((c + 1) & 1) * (P * TM * LDX), tid);
         __syncthreads();
       }
-      acc_to_lds<P, NBW>(acc, H1s, prow1, kCTM * tt, ld1, wave * NBW * 16, d.R1, r, q);
+      acc_to_lds<P, TM, NBW>(acc, H1s, prow1, TM * tt, ld1, wave * NBW * 16, d.R1, r, q);
     }
   }
   __syncthreads();
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
         if (tap >= taps) { tap = taps - 1; }                  // keeps the surplus steps' addresses valid
       }
     }
-    acc_to_lds<P, NBW>(acc, H2s, kCTM, 0, ld2, wave * NBW * 16, d.R2, r, q);
+    acc_to_lds<P, TM, NBW>(acc, H2s, TM, 0, ld2, wave * NBW * 16, d.R2, r, q);
   }
   __syncthreads();
 
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             bf16x8_t a[P];
-            gather_x<P>(a, H2s, kCTM, ld2, t < KS3 ? 16 * mt + r : -1, min(t, KS3 - 1), q);
+            gather_x<P>(a, H2s, TM, ld2, t < KS3 ? 16 * mt + r : -1, min(t, KS3 - 1), q);
             mma_tile<P, NB3>(a, b[u], acc[mt]);
           }
         }
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(256) void tt_conv_kernel(const ConvChainDesc d) {
   }
 }
 
-template <int P, int KC, int NBW, typename T>
+template <int P, int TM, int KC, int NBW, typename T>
 int launch_conv_nbw(const ConvChainDesc& d, hipStream_t s) {
-  auto kern = tt_conv_kernel<P, KC, NBW, T>;
-  const size_t lds = ((size_t)2 * P * kCTM * (KC + kPad) + (size_t)P * kCTM * d.NT * (d.R1 + kPad) + (size_t)P * kCTM * (d.R2 + kPad)) * 2;
+  auto kern = tt_conv_kernel<P, TM, KC, NBW, T>;
+  const size_t lds = ((size_t)2 * P * TM * (KC + kPad) + (size_t)P * TM * d.NT * (d.R1 + kPad) + (size_t)P * TM * (d.R2 + kPad)) * 2;
   if (lds > 160 * 1024) return -1;
   static bool attr_done[64] = {false};
   int devi = 0;
@@ -333,12 +333,12 @@ int launch_conv_nbw(const ConvChainDesc& d, hipStream_t s) {
   return 0;
 }
 
-template <int P, int KC, typename T>
+template <int P, int TM, int KC, typename T>
 int launch_conv_variant(const ConvChainDesc& d, hipStream_t s) {
   const int tiles = (d.R1 > d.R2 ? d.R1 : d.R2) / 16;                  // spread the feature tiles over the four waves
-  if (tiles <= 4) return launch_conv_nbw<P, KC, 1, T>(d, s);
-  if (tiles <= 8) return launch_conv_nbw<P, KC, 2, T>(d, s);
-  return launch_conv_nbw<P, KC, 4, T>(d, s);
+  if (tiles <= 4) return launch_conv_nbw<P, TM, KC, 1, T>(d, s);
+  if (tiles <= 8) return launch_conv_nbw<P, TM, KC, 2, T>(d, s);
+  return launch_conv_nbw<P, TM, KC, 4, T>(d, s);
 }
 
 }  // namespace
@@ -347,8 +347,12 @@ int launch_conv_variant(const ConvChainDesc& d, hipStream_t s) {
 // three-launch path).
 int launch_tt_conv(const ConvChainDesc& d, int dtype, hipStream_t s) {
   if (d.B <= 0) return 0;
-  if (dtype == 1) return launch_conv_variant<1, 128, uint16_t>(d, s);
-  return launch_conv_variant<3, 64, float>(d, s);
+  if (d.TM == 32) {
+    if (dtype == 1) return launch_conv_variant<1, 32, 128, uint16_t>(d, s);
+    return launch_conv_variant<3, 32, 64, float>(d, s);
+  }
+  if (dtype == 1) return launch_conv_variant<1, 64, 128, uint16_t>(d, s);
+  return launch_conv_variant<3, 64, 64, float>(d, s);
 }
 
 }  // namespace tadmm

@@ -1334,16 +1334,8 @@ int tadmm_ttconv_fused(tadmm_handle h, const tadmm_conv_chain_desc* c, void* str
   const int wo = (c->W + 2 * c->pad_w - c->dil_w * (c->kw - 1) - 1) / c->stride_w + 1;
   if (ho != c->Ho || wo != c->Wo) CTX_FAIL(h, TADMM_ERR_INVALID, "conv chain: output size does not match the geometry");
   if (ho <= 0 || wo <= 0 || wo > 64) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: output rows of more than 64 pixels take the three-launch path");
-  // output rows per workgroup: as many as give <= 64 output pixels and a halo of <= 192 input pixels
-  int tr = std::min(ho, 64 / wo), nt = 0;
-  for (; tr >= 1; --tr) {
-    const int irows = std::min(c->H, (tr - 1) * c->stride_h + (c->kh - 1) * c->dil_h + 1);
-    nt = (irows * c->W + 63) / 64;
-    if (nt <= 3) break;
-  }
-  if (tr < 1) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: the halo of one output row exceeds 192 pixels");
-  if (c->R1 <= 0 || c->R2 <= 0 || c->R1 % 32 || c->R2 % 64 || c->R1 > 256 || c->R2 > 256)
-    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: ranks must be padded to 32 / 64 and at most 256");
+  if (c->R1 <= 0 || c->R2 <= 0 || c->R1 % 32 || c->R2 % 32 || c->R1 > 256 || c->R2 > 256)
+    CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: ranks must be padded to multiples of 32 and at most 256");
   const int64_t taps = (int64_t)c->kh * c->kw;
   if ((((uintptr_t)c->W1) & 15) || (((uintptr_t)c->W2) & 15) || (((uintptr_t)c->W3) & 15) || (((uintptr_t)c->bias) & 15) ||
       c->w1_plane < (int64_t)(c->R1 / 16) * ((c->C + 31) / 32) * 512 || c->w2_plane < (int64_t)(c->R2 / 16) * taps * (c->R1 / 32) * 512 ||
@@ -1356,7 +1348,28 @@ int tadmm_ttconv_fused(tadmm_handle h, const tadmm_conv_chain_desc* c, void* str
   d.B = c->B; d.C = c->C; d.R1 = c->R1; d.R2 = c->R2; d.Nout = c->Nout;
   d.H = c->H; d.W = c->W; d.Ho = ho; d.Wo = wo; d.kh = c->kh; d.kw = c->kw; d.sh = c->stride_h; d.sw = c->stride_w;
   d.ph = c->pad_h; d.pw = c->pad_w; d.dh = c->dil_h; d.dw = c->dil_w;
-  d.TR = tr; d.tiles = (ho + tr - 1) / tr; d.NT = nt;
+  {
+    // pixels per workgroup: 64, or 32 when the intermediates of 64 do not fit the LDS; output rows per workgroup: as many
+    // as give <= TM output pixels and a halo of <= 3 TM input pixels
+    const int planes = c->dtype == TADMM_CHAIN_F32 ? 3 : 1, kc = c->dtype == TADMM_CHAIN_F32 ? 64 : 128;
+    bool found = false;
+    for (int tmx = 64; tmx >= 32 && !found; tmx /= 2) {
+      if (wo > tmx) continue;
+      int tr = std::min(ho, tmx / wo), nt = 0;
+      for (; tr >= 1; --tr) {
+        const int irows = std::min(c->H, (tr - 1) * c->stride_h + (c->kh - 1) * c->dil_h + 1);
+        nt = (irows * c->W + tmx - 1) / tmx;
+        if (nt <= 3) break;
+      }
+      if (tr < 1) continue;
+      const size_t lds = ((size_t)2 * planes * tmx * (kc + 8) + (size_t)planes * tmx * nt * (c->R1 + 8) +
+                          (size_t)planes * tmx * (c->R2 + 8)) * 2;
+      if (lds > 160 * 1024) continue;
+      d.TM = tmx; d.TR = tr; d.tiles = (ho + tr - 1) / tr; d.NT = nt;
+      found = true;
+    }
+    if (!found) CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "conv chain: halo or intermediates do not fit the LDS");
+  }
   const int epl = c->dtype == TADMM_CHAIN_F32 ? 4 : 8;
   d.x_vec = ((c->H * c->W) % epl == 0 && (((uintptr_t)c->X) & 15) == 0) ? 1 : 0;
   if (launch_tt_conv(d, c->dtype, (hipStream_t)stream_) != 0)

@@ -92,7 +92,7 @@ def run(device=None, iters: int = 50):
                 wcd = wc.to(dtype)
                 ms = _time(lambda: conv(xc), iters)
                 dense = _time(lambda: F.conv2d(xc, wcd, None, 1, 1), iters)
-                one = ops.conv_chain_fits(xc, conv.in_tt_ranks[0], conv.out_tt_ranks[-1], conv.kernel_size, conv.stride,
+                one = ops.conv_chain_pays(xc, conv.in_tt_ranks[0], conv.out_tt_ranks[-1], conv.kernel_size, conv.stride,
                                           conv.padding, conv.dilation)
                 rows.append(_row("TTConv2dM resnet18 %s (B=64, %dx%d, ranks %s)" % (lname[:-7], hw, hw, conv.tt_ranks), dtype,
                                  ms, dense, None, 0.0, 1 if one else 3))
@@ -105,7 +105,7 @@ def run(device=None, iters: int = 50):
             wkd = wk.to(dtype)
             ms = _time(lambda: tk(xk), iters)
             dense = _time(lambda: F.conv2d(xk, wkd, None, 1, 1), iters)
-            one = ops.conv_chain_fits(xk, tk.in_rank, tk.out_rank, tk.kernel_size, tk.stride, tk.padding, tk.dilation)
+            one = ops.conv_chain_pays(xk, tk.in_rank, tk.out_rank, tk.kernel_size, tk.stride, tk.padding, tk.dilation)
             rows.append(_row("TKConv2dC resnet32 layer3.1.conv1 (B=128, 8x8, ranks [%d, %d])" % (tk.out_rank, tk.in_rank),
                              dtype, ms, dense, None, 0.0, 1 if one else 3))
     return rows

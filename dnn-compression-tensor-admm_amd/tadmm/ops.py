@@ -454,49 +454,68 @@ def chain_single(x, w_planes, bias, n_out: int, entry: str = "tadmm_ttconv_chain
     return _chain_call(entry, x, w_planes, None, bias, kin, n_out, 0, image_out, tile_tokens, prepare_only)
 
 
-def conv_chain_fits(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation) -> bool:
-    """True when the one-launch factorised convolution (csrc/convchain.hip) applies: output rows of at most 64 pixels,
-    a tile of output rows whose halo is at most 192 input pixels, ranks at most 256 and both intermediates inside the
-    160 KiB of LDS (the same rule tadmm_ttconv_fused applies)."""
+def _conv_chain_plan(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation):
+    """(pixels per workgroup, output rows per workgroup, halo tiles, workgroups per image) of the one-launch factorised
+    convolution, or None when it does not apply -- the rule tadmm_ttconv_fused applies."""
     if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
-        return False
+        return None
     H, W = x.shape[2], x.shape[3]
     ho = (H + 2 * padding[0] - dilation[0] * (kernel_size[0] - 1) - 1) // stride[0] + 1
     wo = (W + 2 * padding[1] - dilation[1] * (kernel_size[1] - 1) - 1) // stride[1] + 1
     if ho <= 0 or wo <= 0 or wo > 64:
-        return False
-    r1p, r2p = -(-r1 // 32) * 32, -(-r2 // 64) * 64
+        return None
+    r1p, r2p = -(-r1 // 32) * 32, -(-r2 // 32) * 32
     if r1p > 256 or r2p > 256:
-        return False
-    tr, nt = min(ho, 64 // wo), 0
-    while tr >= 1:
-        irows = min(H, (tr - 1) * stride[0] + (kernel_size[0] - 1) * dilation[0] + 1)
-        nt = -(-(irows * W) // 64)
-        if nt <= 3:
-            break
-        tr -= 1
-    if tr < 1:
-        return False
+        return None
     planes, kc = (3, 64) if x.dtype == torch.float32 else (1, 128)
-    lds = (2 * planes * 64 * (kc + 8) + planes * 64 * nt * (r1p + 8) + planes * 64 * (r2p + 8)) * 2
-    return lds <= 160 * 1024
+    for tm in (64, 32):                                  # pixels per workgroup: 64, or 32 when 64 does not fit the LDS
+        if wo > tm:
+            continue
+        tr, nt = min(ho, tm // wo), 0
+        while tr >= 1:
+            irows = min(H, (tr - 1) * stride[0] + (kernel_size[0] - 1) * dilation[0] + 1)
+            nt = -(-(irows * W) // tm)
+            if nt <= 3:
+                break
+            tr -= 1
+        if tr < 1:
+            continue
+        lds = (2 * planes * tm * (kc + 8) + planes * tm * nt * (r1p + 8) + planes * tm * (r2p + 8)) * 2
+        if lds <= 160 * 1024:
+            return tm, tr, nt, -(-ho // tr)
+    return None
+
+
+def conv_chain_fits(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation) -> bool:
+    """True when the one-launch factorised convolution (csrc/convchain.hip) applies: output rows of at most 64 pixels,
+    a tile of output rows whose halo is at most three pixel tiles, ranks at most 256 and both intermediates inside the
+    160 KiB of LDS."""
+    return _conv_chain_plan(x, r1, r2, kernel_size, stride, padding, dilation) is not None
+
+
+def conv_chain_pays(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation) -> bool:
+    """... and is the faster path (measured, scripts/bench_conv_layers.py): always in bf16; in fp32 (three planes, six
+    MFMA products per product) only while an image is at most two workgroups -- with more row tiles the recomputed halos
+    cost more than the two launches and the round trip of the intermediates they save."""
+    plan = _conv_chain_plan(x, r1, r2, kernel_size, stride, padding, dilation)
+    return plan is not None and (x.dtype == torch.bfloat16 or plan[3] <= 2)
 
 
 def conv_core_planes(core: torch.Tensor, planes: int) -> torch.Tensor:
     """(r2, r1, kh, kw) core kernel -> fragment-major planes of the (r2 x kh*kw*r1p) tap-major matrix convchain.hip
-    multiplies with (r1p = r1 rounded up to 32, rows rounded up to 64)."""
+    multiplies with (r1p = r1 rounded up to 32, rows rounded up to 32)."""
     r2, r1, kh, kw = core.shape
     r1p = -(-r1 // 32) * 32
     m = torch.zeros(r2, kh * kw, r1p, dtype=torch.float32, device=core.device)
     m[:, :, :r1] = core.detach().float().permute(0, 2, 3, 1).reshape(r2, kh * kw, r1)
-    return weight_planes(m.reshape(r2, kh * kw * r1p), planes, pad_rows=64)
+    return weight_planes(m.reshape(r2, kh * kw * r1p), planes, pad_rows=32)
 
 
 def conv_chain(x: torch.Tensor, w1p: torch.Tensor, w2p: torch.Tensor, w3p: torch.Tensor, bias, n_out: int, kernel_size,
                stride, padding, dilation) -> torch.Tensor:
     """y (B, n_out, Ho, Wo) = W3 conv_kxk(W1 x; Wc) + bias for NCHW images in one launch (`tadmm_ttconv_fused`; see
     `conv_chain_fits` for what is eligible).
-    w1p = weight_planes(W1, P, pad_rows=32), w2p = conv_core_planes(core, P), w3p = weight_planes(W3, P, pad_cols=64)."""
+    w1p = weight_planes(W1, P, pad_rows=32), w2p = conv_core_planes(core, P), w3p = weight_planes(W3, P)."""
     if not x.is_cuda:
         raise TadmmError(-1, "x must live on a HIP device; there is no CPU path")
     if not x.is_contiguous():

@@ -117,7 +117,7 @@ class TKConv2dC(_TKConvBase):
 
     def _fused(self, x, w1, core, w3):
         """The whole layer in one launch when the planes are small (csrc/convchain.hip); None when it does not apply."""
-        if torch.is_grad_enabled() or self.groups != 1 or not ops.conv_chain_fits(
+        if torch.is_grad_enabled() or self.groups != 1 or not ops.conv_chain_pays(
                 x, w1.shape[0], w3.shape[1], self.kernel_size, self.stride, self.padding, self.dilation):
             return None
         n = 1 if x.dtype == torch.bfloat16 else 3
@@ -125,7 +125,7 @@ class TKConv2dC(_TKConvBase):
         key = (n, x.device, w1._version, core._version, w3._version)
         if cache.get("key") != key:
             cache.update(key=key, planes=(ops.weight_planes(w1.detach(), n, pad_rows=32), ops.conv_core_planes(core, n),
-                                          ops.weight_planes(w3.detach(), n, pad_cols=64)))
+                                          ops.weight_planes(w3.detach(), n)))
         p1, p2, p3 = cache["planes"]
         return ops.conv_chain(x, p1, p2, p3, self.bias, self.out_channels, self.kernel_size, self.stride, self.padding,
                               self.dilation)

@@ -179,13 +179,13 @@ class TTConv2dM(_TTConvBase):
                     w_in, w_out = self._factors()
                 cache.update(key=key, w=(w_in, w_out), planes=(HF.planes_of(w_in, n), HF.planes_of(w_out, n)))
             (w_in, w_out), (p_in, p_out) = cache["w"], cache["planes"]
-        if not grad and self.groups == 1 and ops.conv_chain_fits(x, w_in.shape[0], w_out.shape[1], self.kernel_size,
+        if not grad and self.groups == 1 and ops.conv_chain_pays(x, w_in.shape[0], w_out.shape[1], self.kernel_size,
                                                                   self.stride, self.padding, self.dilation):
             # small planes (<= 64 pixels): the whole layer in ONE launch, both intermediates in LDS (csrc/convchain.hip)
             fkey = (key, "fused")
             if cache.get("fkey") != fkey:
                 cache.update(fkey=fkey, fplanes=(ops.weight_planes(w_in, n, pad_rows=32), ops.conv_core_planes(self.core_kernel, n),
-                                                 ops.weight_planes(w_out, n, pad_cols=64)))
+                                                 ops.weight_planes(w_out, n)))
             f1, f2, f3 = cache["fplanes"]
             return ops.conv_chain(x, f1, f2, f3, self.bias, self.out_channels, self.kernel_size, self.stride, self.padding,
                                   self.dilation)

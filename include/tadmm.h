@@ -247,8 +247,8 @@ int tadmm_tucker_1x1(tadmm_handle h, const tadmm_chain_desc* d, void* stream);
  * for NCHW tensors with output rows of at most 64 pixels: one workgroup per tile of output rows (<= 64 output pixels, a halo of
  * <= 192 input pixels); the two intermediates stay in LDS.  TTConv2dM
  * (TTConv.py:130-153), TKConv2dC / TKConv2dM (TKConv.py:93-98, :210-214).  W1 (R1 x C), W2 (R2 x kh*kw*R1, tap-major:
- * column (dy*kw + dx)*R1 + c) and W3 (Nout x R2) are fragment-major bf16 planes as for tadmm_chain_desc, R1 a multiple of
- * 32 and R2 of 64 (zero padded), both <= 256; groups = 1.  Returns TADMM_ERR_UNSUPPORTED when the image or the
+ * column (dy*kw + dx)*R1 + c) and W3 (Nout x R2) are fragment-major bf16 planes as for tadmm_chain_desc, R1 and R2
+ * multiples of 32 (zero padded), both <= 256; groups = 1.  Returns TADMM_ERR_UNSUPPORTED when the image or the
  * intermediates do not fit (the caller then uses tadmm_ttconv_chain_in / conv2d / tadmm_ttconv_chain_out). */
 typedef struct {
   const void* X; void* Y;

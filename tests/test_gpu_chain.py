@@ -188,6 +188,8 @@ def test_ttlinearm_fused_backward_matches_fp64_autograd():
     (2, 16, 56, 56, 12, 16, 24, 3, 1, 1, 1),     # 56x56: one output row per workgroup, 3 x 56 pixels of halo
     (2, 48, 14, 14, 20, 20, 32, 3, 2, 1, 1),     # stride 2: 14x14 -> 7x7 in one tile, halo = the whole input plane (196 px: NT > 3 -> smaller tile)
     (2, 24, 20, 12, 16, 16, 24, 5, 1, 2, 1),     # non-square plane, 5x5 taps
+    (4, 128, 7, 7, 220, 220, 96, 3, 1, 1, 1),    # TT ranks: in fp32 the three planes only fit with 32 pixels per workgroup
+    (3, 64, 14, 14, 138, 138, 80, 3, 1, 1, 1),   # ResNet-18 layer3 ranks (fp32: 32-pixel tiles, two rows each)
 ])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_chain_matches_three_torch_convs(B, C, H, W, r1, r2, O, k, stride, pad, dil, dtype):
@@ -202,7 +204,7 @@ def test_conv_chain_matches_three_torch_convs(B, C, H, W, r1, r2, O, k, stride, 
     n = 3 if dtype == torch.float32 else 1
     ks, st, pd, dl = (k, k), (stride, stride), (pad, pad), (dil, dil)
     assert ops.conv_chain_fits(x, r1, r2, ks, st, pd, dl)
-    p1, p2, p3 = ops.weight_planes(w1, n, pad_rows=32), ops.conv_core_planes(core, n), ops.weight_planes(w3, n, pad_cols=64)
+    p1, p2, p3 = ops.weight_planes(w1, n, pad_rows=32), ops.conv_core_planes(core, n), ops.weight_planes(w3, n)
     y = ops.conv_chain(x, p1, p2, p3, bias, O, ks, st, pd, dl)
     # reference in fp64 on the weights the kernel sees (bf16 mode: rounded to bf16)
     q = (lambda t: t.double()) if dtype == torch.float32 else (lambda t: t.to(torch.bfloat16).double())
@@ -242,12 +244,15 @@ def test_small_image_conv_layers_take_the_fused_launch(monkeypatch):
         y3 = layer(x)                                        # grad mode: three launches, differentiable
         assert len(calls) == n0 + 1 and y3.requires_grad
         assert (y - y3.detach()).abs().max().item() < 5e-6 * y3.abs().max().item()
-        big = torch.randn(2, 64, 14, 14, device="cuda")      # 196 pixels: row tiles, still one launch
+        big = torch.randn(2, 64, 14, 14, device="cuda")      # 196 pixels = four row tiles per image
         with torch.no_grad():
-            yb = layer(big)
+            layer(big)                                       # fp32: fits, but does not pay -> three launches
+        assert len(calls) == n0 + 1
+        with torch.no_grad():
+            yb = layer(big.bfloat16())                       # bf16: one launch
         assert len(calls) == n0 + 2
         yb3 = layer(big)
-        assert (yb - yb3.detach()).abs().max().item() < 5e-6 * yb3.abs().max().item()
+        assert (yb.float() - yb3.detach()).abs().max().item() < 3e-2 * yb3.abs().max().item()
         wide = torch.randn(1, 64, 4, 80, device="cuda")      # rows of 80 pixels: three launches
         with torch.no_grad():
             layer(wide)

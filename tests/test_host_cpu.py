@@ -247,7 +247,8 @@ def test_chain_eligibility_rules_are_pure_host_logic():
     x = torch.zeros(2, 64, 8, 8)
     assert ops.conv_chain_fits(x, 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))
     assert ops.conv_chain_fits(x.to(torch.bfloat16), 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))
-    assert not ops.conv_chain_fits(x, 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))          # three planes of 224: > 160 KiB
+    assert ops.conv_chain_fits(x, 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))              # three planes of 224: 32-pixel tiles
+    assert not ops.conv_chain_fits(torch.zeros(2, 64, 14, 14), 250, 250, (5, 5), (1, 1), (2, 2), (1, 1))   # 5 halo rows of 256 ch
     assert ops.conv_chain_fits(torch.zeros(2, 64, 14, 14), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))       # row tiles
     assert not ops.conv_chain_fits(torch.zeros(2, 8, 112, 112), 8, 8, (3, 3), (1, 1), (1, 1), (1, 1))    # rows of 112 pixels
     assert not ops.conv_chain_fits(torch.zeros(2, 8, 56, 56), 8, 8, (7, 7), (1, 1), (3, 3), (1, 1))      # halo of 7 rows > 192 px
@@ -255,6 +256,11 @@ def test_chain_eligibility_rules_are_pure_host_logic():
     assert not ops.conv_chain_fits(x.double(), 23, 25, (3, 3), (1, 1), (1, 1), (1, 1))
     assert ops.conv_chain_fits(x, 23, 25, (3, 3), (2, 2), (1, 1), (1, 1))                 # stride 2: 8x8 -> 4x4
     assert not ops.conv_chain_fits(x, 23, 25, (9, 9), (1, 1), (0, 0), (1, 1))             # empty output plane
+    # capability vs choice: fp32 with many row tiles fits but does not pay; bf16 always takes it
+    big = torch.zeros(2, 64, 28, 28)
+    assert ops.conv_chain_fits(big, 72, 72, (3, 3), (1, 1), (1, 1), (1, 1)) and not ops.conv_chain_pays(big, 72, 72, (3, 3), (1, 1), (1, 1), (1, 1))
+    assert ops.conv_chain_pays(big.to(torch.bfloat16), 72, 72, (3, 3), (1, 1), (1, 1), (1, 1))
+    assert ops.conv_chain_pays(x, 220, 220, (3, 3), (1, 1), (1, 1), (1, 1))              # 8x8 fp32: two workgroups per image
     assert HF.fused_rank_ok(256) and not HF.fused_rank_ok(257) and not HF.fused_rank_ok(0)
 
 
