@@ -28,6 +28,9 @@ sys.path.insert(0, os.path.join(ROOT, "dnn-compression-tensor-admm_amd"))
 sys.path.insert(0, ROOT)
 
 PEAK_F64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (vendor figure; = fp64 vector peak on CDNA4)
+# what v_mfma_f64_16x16x4 sustains on this part, register operands only (scripts/micro/mfma_f64_peak.hip): 24 TF/s on one
+# accumulator chain, 33-35 on 4-8 independent ones at one wave per SIMD, 45.3 at two waves per SIMD
+PEAK_F64_MFMA_MEASURED_TFLOPS = 45.3
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0
 
@@ -292,13 +295,16 @@ def main():
                 "bound": "mfma", "kernel": "dgemm_nt_tile_kernel<32,1> (fp64 MFMA 16x16x4: block products of the "
                                            "filtered eigen-solver)",
                 "achieved": gemm_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F64_MFMA_TFLOPS,
+                "peak_measured": PEAK_F64_MFMA_MEASURED_TFLOPS, "frac_of_measured": gemm_tf / PEAK_F64_MFMA_MEASURED_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": "profiles/r02_pmc_traffic.json (per launch)" if traffic else None,
                 "launches_per_step": ft["gemm_launches"] / reps,
                 "avg_launch_us": 1e3 * ft["gemm_ms"] / ft["gemm_launches"],
                 "time_share": (ft["gemm_ms"] / reps) / max(1e-9, total_ms),
                 "flops_per_step": ft["gemm_flops"] / reps,
-                "note": "dominant kernel by time.  achieved = 2*M*N*K of every product the launches executed "
+                "note": "dominant kernel by time.  peak = vendor fp64 matrix figure; peak_measured = what v_mfma_f64_16x16x4 "
+                        "sustains here with register operands (scripts/micro/mfma_f64_peak.hip; 33-35 TF/s at this "
+                        "kernel's one wave per SIMD).  achieved = 2*M*N*K of every product the launches executed "
                         "(gated-off problems excluded; read back from the device) / their HIP-event time, each launch "
                         "timed on the launch stream.  These FLOPs are the work of the filter, not part of the "
                         "thin-SVD model"}

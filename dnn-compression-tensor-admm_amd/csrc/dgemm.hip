@@ -33,6 +33,13 @@ __device__ __forceinline__ const double* dg_sel(const DgemmDesc& d, int sel, con
   return d.ring[i];
 }
 
+#ifdef TADMM_DGEMM_STAMPS
+__device__ long long g_dstamps[64];
+#define DSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dstamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+
 template <bool kBT>
 __global__ __launch_bounds__(256) void dgemm_kernel(const DgemmDesc* __restrict__ descs,
                                                     const BlockRef* __restrict__ map) {
@@ -245,11 +252,11 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
 #pragma unroll
     for (int i = 0; i < BP; ++i) *reinterpret_cast<double2_t*>(&Bs[srow + RS * i][2 * sc2]) = R.b[i];
   };
-  double4_t acc[2][NB];
+  double4_t acc[2][NB], accb[2][NB];     // even / odd k-steps
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = double4_t{0, 0, 0, 0};
+    for (int j = 0; j < NB; ++j) acc[i][j] = accb[i][j] = double4_t{0, 0, 0, 0};
   auto compute = [&](int stage) {
     if (!live) return;
     const double (*As)[kDLd] = reinterpret_cast<const double (*)[kDLd]>(smem + stage * kBuf);
@@ -268,15 +275,22 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
 #pragma unroll
       for (int j = 0; j < NB; ++j) fb[s][j] = b0p[16 * j * kDLd + 4 * s];
     }
+    // v_mfma_f64_16x16x4 is latency-bound on a short accumulator chain (scripts/micro/mfma_f64_peak.hip: 210 cycles per
+    // MFMA on one accumulator, 150 on four, 111 with two waves per SIMD): even and odd k-steps go to separate
+    // accumulators, which doubles the independent chains of a wave without touching the tile or the operand traffic.
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int s = 0; s < KS; s += 2) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s], fb[s][j], acc[0][j], 0, 0, 0);
         acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s], fb[s][j], acc[1][j], 0, 0, 0);
+        accb[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s + 1], fb[s + 1][j], accb[0][j], 0, 0, 0);
+        accb[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s + 1], fb[s + 1][j], accb[1][j], 0, 0, 0);
       }
     }
+    static_assert(KS % 2 == 0, "k-steps of a chunk are paired");
   };
+  DSTAMP(0);
   const int nch = K / kDK;
   constexpr int NPF = 2;                 // register sets: a chunk's loads are issued NPF chunks before its LDS store (deeper: no gain)
   Regs R[NPF];
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   sstore(R[0], 0);
   if (NPF < nch) gload(R[0], NPF * kDK);
   __syncthreads();
+  DSTAMP(1);
   for (int c = 0; c < nch; c += NPF) {
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
@@ -296,10 +311,16 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
           if (i + 1 + NPF < nch) gload(R[(u + 1) % NPF], (i + 1 + NPF) * kDK);
         }
         compute(u & 1);
+        DSTAMP(2 + 2 * i);
         __syncthreads();
+        DSTAMP(3 + 2 * i);
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] += accb[i][j];
   // accumulators -> LDS tile [64][TN+1] (aliases the staging buffers; the loop's last barrier has passed)
   double (*Ct)[TN + 1] = reinterpret_cast<double (*)[TN + 1]>(smem);
   if (KW == 2) {                        // upper k-half first, then the lower half adds its own sums
@@ -363,6 +384,7 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
       }
     }
   }
+  DSTAMP(40);
   if (mode >= 2) {
     rowred[row][tid & 3] = part;
     __syncthreads();
@@ -375,6 +397,16 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
 
 void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n) {
   if (nblocks <= 0) return;
+#ifdef TADMM_DGEMM_STAMPS
+  if (getenv("TADMM_DGEMM_STAMPS_DUMP")) {
+    long long h[64];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dstamps), sizeof h);
+    fprintf(stderr, "[dgemm stamps]");
+    for (int i = 1; i < 41; ++i) if (h[i]) fprintf(stderr, " %d:%lld", i, h[i] - h[0]);
+    fprintf(stderr, "\n");
+  }
+#endif
   static const int kw = getenv("TADMM_DGEMM_KW") ? atoi(getenv("TADMM_DGEMM_KW")) : 1;      // 2: eight-wave variant (A/B)
   if (tile_n == 32) {
     if (kw == 2) hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 2>), dim3(nblocks), dim3(512), 0, s, descs_dev, map_dev);
