@@ -252,11 +252,11 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
 #pragma unroll
     for (int i = 0; i < BP; ++i) *reinterpret_cast<double2_t*>(&Bs[srow + RS * i][2 * sc2]) = R.b[i];
   };
-  double4_t acc[2][NB], accb[2][NB];     // even / odd k-steps
+  double4_t acc[2][NB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = accb[i][j] = double4_t{0, 0, 0, 0};
+    for (int j = 0; j < NB; ++j) acc[i][j] = double4_t{0, 0, 0, 0};
   auto compute = [&](int stage) {
     if (!live) return;
     const double (*As)[kDLd] = reinterpret_cast<const double (*)[kDLd]>(smem + stage * kBuf);
@@ -275,20 +275,16 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
 #pragma unroll
       for (int j = 0; j < NB; ++j) fb[s][j] = b0p[16 * j * kDLd + 4 * s];
     }
-    // v_mfma_f64_16x16x4 is latency-bound on a short accumulator chain (scripts/micro/mfma_f64_peak.hip: 210 cycles per
-    // MFMA on one accumulator, 150 on four, 111 with two waves per SIMD): even and odd k-steps go to separate
-    // accumulators, which doubles the independent chains of a wave without touching the tile or the operand traffic.
+    // (two accumulators per wave; splitting them by k-step parity into four independent chains changes nothing: the
+    // instruction issues at ~150 cycles at one wave per SIMD whatever the chain length, scripts/micro/mfma_f64_peak.hip)
 #pragma unroll
-    for (int s = 0; s < KS; s += 2) {
+    for (int s = 0; s < KS; ++s) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s], fb[s][j], acc[0][j], 0, 0, 0);
         acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s], fb[s][j], acc[1][j], 0, 0, 0);
-        accb[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[s + 1], fb[s + 1][j], accb[0][j], 0, 0, 0);
-        accb[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[s + 1], fb[s + 1][j], accb[1][j], 0, 0, 0);
       }
     }
-    static_assert(KS % 2 == 0, "k-steps of a chunk are paired");
   };
   DSTAMP(0);
   const int nch = K / kDK;
@@ -317,10 +313,6 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] += accb[i][j];
   // accumulators -> LDS tile [64][TN+1] (aliases the staging buffers; the loop's last barrier has passed)
   double (*Ct)[TN + 1] = reinterpret_cast<double (*)[TN + 1]>(smem);
   if (KW == 2) {                        // upper k-half first, then the lower half adds its own sums
