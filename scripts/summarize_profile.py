@@ -33,6 +33,8 @@ if os.path.exists(b):
 st = find("trace/**/*kernel_stats.csv")
 if st:
     print("\n## kernel stats (--kernel-trace --stats)\n")
+    print("(naive_conv_*, miopen*, igemm_*, Im2d2Col*, Cijk_* and ck:: rows are the DENSE torch layers the forward block of bench.py times as baselines,\n"
+          "including MIOpen's first-call algorithm search; they are not part of the projection step or of the chain kernels)\n")
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
     for row in csv.DictReader(open(st)):
