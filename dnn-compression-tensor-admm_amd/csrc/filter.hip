@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void filt_plan_kernel(const FiltProb* __restri
     const double l1 = sorted[0], lr = sorted[p.r - 1], b = sorted[rp - 1];
     bool ok = isfinite(l1) && isfinite(b) && b > 0.0 && lr > b * (1.0 + 1e-9) && l1 >= lr;
     int m = 0;
+    bool more = false;
     if (ok) {
       const double e = 0.5 * b, c = 0.5 * b;             // damped interval [0, b]
       const double xr = (lr - c) / e, x1 = (l1 - c) / e;
@@ -123,6 +124,11 @@ __global__ __launch_bounds__(256) void filt_plan_kernel(const FiltProb* __restri
         st->coef1[0] = 1.0 / e; st->coef1[1] = -c / e;
         st->coefk[0] = 2.0 / e; st->coefk[1] = -2.0 * c / e; st->coefk[2] = -1.0;
         if (!(stage_fast & 1)) { st->precise_stages += 1; st->logamp_precise += m * ar - ln2; }
+        // what is still missing AFTER this stage is known now (the amplification is accounted from the bounds, not
+        // measured): the problem drops out of the next stage's launches here, not after another product + plan
+        double after = prm.log_target - st->logamp;
+        if (st->products_fast > 0 || (stage_fast & 1)) after = fmax(after, prm.log_precise - st->logamp_precise);
+        more = after > 0.0;
       }
       st->b = b; st->lr = lr; st->l1 = l1;
     } else {
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(256) void filt_plan_kernel(const FiltProb* __restri
     int res = st->base + m;
     res -= (res >= 3) ? 3 : 0; res -= (res >= 3) ? 3 : 0; res -= (res >= 3) ? 3 : 0;
     st->res = res % 3;
-    st->active = (m > 0 && !last_stage) ? 1 : 0;
+    st->active = (m > 0 && more && !last_stage) ? 1 : 0;
     st->stage += 1;
-    verdict[1 + blockIdx.x] = m > 0 ? 1 : 0;
+    verdict[1 + blockIdx.x] = (m > 0 ? 1 : 0) | (st->active ? 2 : 0);     // bit 0: this stage filters, bit 1: wants another
   }
 }
 

@@ -372,9 +372,10 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   int smax = 12;
   if (const char* e = getenv("TADMM_FILTER_STAGES")) smax = std::max(1, atoi(e));
   int stages = 0;
-  // The stage logic runs on the device (gates); the host only has to stop launching.  It reads the verdict of stage
-  // st-1 ("did anyone filter?") after stage st's product + plan launches are queued, so it never waits for the GPU;
-  // the price is one stage of gated (empty) launches at the end.
+  // The stage logic runs on the device (gates); the host only has to stop launching.  A stage's plan already knows
+  // whether its problem will want another stage (bit 1 of its verdict); the host reads the verdict of stage st-1 after
+  // stage st's product + plan launches are queued, so it never waits for the GPU, and the price of the late read is
+  // those two (gated, empty) launches at the end.
   for (int st = 0; st < smax; ++st) {
     const bool fast = st < nfast;
     if (fast) gemm3(fg.p1_f); else gemm(fg.p1);
@@ -384,10 +385,10 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
     if (st > 0) {
       HIP_OK(h, hipEventSynchronize(poll.ev[(st - 1) & 1]));
       const int* prev = poll.host + (size_t)((st - 1) & 1) * poll.stride;
-      bool any = false;
-      for (int q = 0; q < fg.nf; ++q) any = any || prev[1 + q] != 0;
-      if (!any) break;
-      ++stages;
+      bool ran = false, more = false;
+      for (int q = 0; q < fg.nf; ++q) { ran = ran || (prev[1 + q] & 1); more = more || (prev[1 + q] & 2); }
+      if (ran) ++stages;
+      if (!more) break;            // nobody takes part in stage st: its product and plan above were gated off
     }
     launch_daxpby((const DgemmDesc*)D(fg.axpby.desc_off), (const BlockRef*)D(fg.axpby.map_off), fg.axpby.nblocks, s);
     if (fast) for (const Phase& ph : fg.steps_f) gemm3(ph);
