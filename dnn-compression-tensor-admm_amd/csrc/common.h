@@ -76,7 +76,8 @@ struct EigDesc {
   double* sblk;       // [Npad/16][16*16] carried self-Gram of every 16-column super-block (tick3), nullable
   int32_t ldo;        // leading dimension of out_a (0: r)
 };
-void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr);
+void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr,
+                        double* prev_dev = nullptr);   // prev_dev: [nprob] history of jacobi_conv_kernel, reset here
 // device-side convergence decision after a global sweep (prev_dev: [nprob] doubles, zeroed by the caller per run;
 // verdict_pinned: [1 + nprob] ints of device-visible pinned host memory)
 void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,

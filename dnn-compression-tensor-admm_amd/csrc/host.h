@@ -246,8 +246,7 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
       return TADMM_OK;
     }
   }
-  launch_jacobi_init(g.ed, g.neig, s, g.skip);
-  HIP_OK(h, hipMemsetAsync(g.prev_dev, 0, (size_t)g.neig * 8, s));
+  launch_jacobi_init(g.ed, g.neig, s, g.skip, g.prev_dev);
   if (g.gsteps == 0) return TADMM_OK;      // every problem is a single block: nothing to rotate
   bool all_done = false;
   int tick = 0, gs = 0, pending = -1, needed = 0;

@@ -1521,6 +1521,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
     conv = hdone || hoff[gs & 1] < tol;
   }
   if (sweeps_out) *sweeps_out = gs;
+  if (getenv("TADMM_STAMPS_DUMP")) { (void)hipStreamSynchronize(s); dump_stamps(); }   // -DTADMM_STAMPS builds only
   if (!conv) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in 40 sweeps");
   launch_eig_norms(edev, m_norm, (int)vn.size(), s);
   launch_eig_sort(edev, 1, s);
