@@ -26,7 +26,7 @@ constexpr int kCMaxT = 16;         // n <= 256
 __device__ __forceinline__ double rsqrt_f64(double x) {
   double y = __builtin_amdgcn_rsq(x);                    // ~2^-26 relative
   y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);                       // (second step kept: 16 pivots in a row feed one another)
   return y;
 }
 
@@ -101,6 +101,22 @@ __device__ __forceinline__ bool diag_inverse(const double (*Dg)[kCLd], double (*
   return ok;
 }
 
+#ifdef TADMM_CHOL_STAMPS
+__device__ long long g_cstamps[128];
+#define CSTAMP(i) do { if (blockIdx.x == 0 && lane == 0) g_cstamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+
+// Barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores (vmcnt(0));
+// the factor rows and inverse tiles this kernel writes to memory are never read back by it, and waiting for their
+// write acknowledgements at three barriers per step cost ~3 k cycles of every 12 k-cycle step (scripts/stamp_chol.sh).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Wave 0 owns no tiles: it only inverts diagonal tiles, and does so for step k WHILE the other seven waves finish
 // the trailing update of step k-1 (look-ahead: the owner of tile (k,k) updates it first and hands it over).
 constexpr int kCTileWaves = 7;
@@ -142,23 +158,38 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
   if (wave == 0) {
     // ---------------- diagonal wave ----------------
     for (int k = 0; k < nbt; ++k) {
-      __syncthreads();                                             // A_k: tile (k,k) is in Dg
+      lds_barrier();                                               // A_k: tile (k,k) is in Dg
+      CSTAMP(3 * k);
       if (!diag_inverse(Dg, Cb, Wt, d.Wd + (int64_t)k * (kCT * kCT), lane, tiny) && lane == 0) fail = 1;
-      __syncthreads();                                             // B_k: W_k is in Wt (and trailing k-1 is complete)
+      CSTAMP(3 * k + 1);
+      lds_barrier();                                               // B_k: W_k is in Wt (and trailing k-1 is complete)
       if (fail) { if (tid == 0) *d.bad = 1; return; }
-      __syncthreads();                                             // C_k: panel k is in Pn
+      lds_barrier();                                               // C_k: panel k is in Pn
+      CSTAMP(3 * k + 2);
     }
     return;
   }
   // ---------------- tile waves ----------------
   const int tw = wave - 1;
   double4_t acc[kCSlots7];
+  // tile coordinates of this wave's slots, read from the LDS table ONCE (packed, one vector register per slot): looked
+  // up per slot and step -- two dependent LDS reads in front of every branch -- they cost the panel phase ~3 k cycles of
+  // a 12 k-cycle step.  WHICH slots take part in a step is scalar arithmetic on the tile index: tiles are numbered row
+  // by row, so rows >= k are the indices >= tkk and row k is [tkk, tkk + nbt - k).
+  int sij[kCSlots7];
+  auto row_of = [](int v) { return v & 0xff; };
+  auto col_of = [](int v) { return v >> 8; };
+  // the LDS addresses derived from a slot's coordinates are loop invariant; hoisted out of the step loop for all 20 slots
+  // they would cost 40 vector registers and spill.  The empty volatile asm makes the compiler rebuild them where used.
+  auto fresh = [](int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; };
 #pragma unroll
   for (int s = 0; s < kCSlots7; ++s) {
     const int t = kCTileWaves * s + tw;
     acc[s] = double4_t{0, 0, 0, 0};
+    sij[s] = 0;
     if (t < ntile) {
-      const int i = __builtin_amdgcn_readfirstlane(ti[t]), j = __builtin_amdgcn_readfirstlane(tj[t]);
+      const int i = ti[t], j = tj[t];
+      sij[s] = (j << 8) | i;
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[s][e] = d.C[(int64_t)(kCT * i + q + 4 * e) * d.ldc + kCT * j + r];
     }
@@ -181,19 +212,19 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
   };
   give_diag(0);
   for (int k = 0; k < nbt; ++k) {
-    __syncthreads();                                               // A_k
+    lds_barrier();                                                 // A_k
     // trailing update of step k-1 for everything but tile (k,k), which was updated before it was handed over
     if (k > 0) {
       const int tkk = k * nbt - (k * (k - 1)) / 2;
 #pragma unroll
       for (int s = 0; s < kCSlots7; ++s) {
         const int t = kCTileWaves * s + tw;
-        const int i = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
-        if (i > k - 1 && t != tkk) trail(acc[s], i, __builtin_amdgcn_readfirstlane(tj[t]));
+        if (t > tkk && t < ntile) { const int c = fresh(sij[s]); trail(acc[s], row_of(c), col_of(c)); }
         __builtin_amdgcn_sched_barrier(0);     // keep the operand loads of one slot from being hoisted over the others
       }
     }
-    __syncthreads();                                               // B_k
+    if (wave == 1) CSTAMP(64 + 2 * k);
+    lds_barrier();                                                 // B_k
     if (fail) return;
     // ---- panel R_kj = W C_kj (j > k) ----
     {
@@ -203,9 +234,9 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
 #pragma unroll
       for (int s = 0; s < kCSlots7; ++s) {
         const int t = kCTileWaves * s + tw;
-        const int pi = t < ntile ? __builtin_amdgcn_readfirstlane(ti[t]) : -1;
-        const int pj = t < ntile ? __builtin_amdgcn_readfirstlane(tj[t]) : -1;
-        if (pi == k && pj > k) {
+        const int tkk = k * nbt - (k * (k - 1)) / 2;
+        if (t > tkk && t < tkk + nbt - k) {
+          const int pj = col_of(fresh(sij[s]));
           double4_t o = {0, 0, 0, 0};
 #pragma unroll
           for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[e], acc[s][e], o, 0, 0, 0);
@@ -219,7 +250,8 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();                                               // C_k
+    if (wave == 1) CSTAMP(65 + 2 * k);
+    lds_barrier();                                                 // C_k
     // ---- look-ahead: bring tile (k+1,k+1) up to date with panel k and hand it over ----
     if (k + 1 < nbt) {
       const int tnn = (k + 1) * nbt - ((k + 1) * k) / 2;
@@ -233,6 +265,17 @@ __global__ __launch_bounds__(512) void chol_factor_kernel(const CholDesc* __rest
 
 void launch_chol_factor(const CholDesc* descs_dev, int nprob, hipStream_t s) {
   if (nprob <= 0) return;
+#ifdef TADMM_CHOL_STAMPS
+  if (getenv("TADMM_CHOL_STAMPS_DUMP")) {
+    long long h[128];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cstamps), sizeof h);
+    fprintf(stderr, "[chol stamps] step: diag | wait B | panel+C | (tile wave: trail done, panel done, relative to A_k)\n");
+    for (int k = 0; k < 16 && h[3 * k + 2]; ++k)
+      fprintf(stderr, "  k=%2d A_k@%6lld  diag %5lld  toC %5lld   trail@%5lld panel@%5lld\n", k, h[3 * k] - h[0], h[3 * k + 1] - h[3 * k],
+              h[3 * k + 2] - h[3 * k + 1], h[64 + 2 * k] - h[3 * k], h[65 + 2 * k] - h[3 * k]);
+  }
+#endif
   hipLaunchKernelGGL(chol_factor_kernel, dim3(nprob), dim3(512), 0, s, descs_dev);
 }
 
@@ -283,16 +326,21 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(const CholDesc* __restr
       }
       fetch(kb + 1);
       if (active) {
-        double4_t acc;
+        // two accumulator chains (even / odd j): a single chain of up to 60 dependent MFMAs was the latency floor of a step
+        double4_t acc, acc1 = {0, 0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = Y[(int64_t)(kCT * kb + q + 4 * e) * ldy + col];
 #pragma unroll
         for (int j = 0; j < kb; ++j) {
           // A[m][kk] = R[16j + kk][16kb + m], kk = q + 4e (the k order of the D-layout B operand X[j])
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Rs[kb & 1][j * (kCT * kCT) + (q + 4 * e) * kCT + r], X[j][e], acc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            const double a = -Rs[kb & 1][j * (kCT * kCT) + (q + 4 * e) * kCT + r];
+            if (j & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][e], acc1, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][e], acc, 0, 0, 0);
+          }
         }
+        acc += acc1;
         double4_t o = {0, 0, 0, 0};
         const G<const double>* W = Wd + (int64_t)kb * (kCT * kCT);
 #pragma unroll
