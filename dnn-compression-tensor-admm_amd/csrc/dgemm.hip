@@ -25,12 +25,41 @@ namespace tadmm {
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ const double* dg_sel(const DgemmDesc& d, int sel, const double* explicit_ptr, int base) {
+// The descriptor as the kernels use it: every field copied by name from global memory (one batch of scalar loads) and
+// the ring as three separate members.  `const DgemmDesc d = descs[i]` followed by the run-time indexed `d.ring[k]` made
+// the compiler keep the whole 192-byte copy in SCRATCH (vector loads of the descriptor, a scratch store of all of it, a
+// scratch load per field): that was a large part of the fixed cost of every launch of these kernels.
+struct DgemmArgs {
+  const double *A, *B, *C, *P, *Q;
+  double *ring0, *ring1, *ring2;
+  const int32_t* rot;
+  int32_t selA, selB, selC, selP, selQ;
+  int32_t M, N, K, lda, ldb, ldc, tiles_m, tiles_n, mode;
+  const double* coef; const double* theta; double* rowpart;
+  const int32_t* gate; int32_t gate_min;
+};
+__device__ __forceinline__ DgemmArgs dg_args(const DgemmDesc* __restrict__ g) {
+  DgemmArgs d;
+  d.A = g->A; d.B = g->B; d.C = g->C; d.P = g->P; d.Q = g->Q;
+  d.ring0 = g->ring[0]; d.ring1 = g->ring[1]; d.ring2 = g->ring[2];
+  d.rot = g->rot;
+  d.selA = g->selA; d.selB = g->selB; d.selC = g->selC; d.selP = g->selP; d.selQ = g->selQ;
+  d.M = g->M; d.N = g->N; d.K = g->K; d.lda = g->lda; d.ldb = g->ldb; d.ldc = g->ldc;
+  d.tiles_m = g->tiles_m; d.tiles_n = g->tiles_n; d.mode = g->mode;
+  d.coef = g->coef; d.theta = g->theta; d.rowpart = g->rowpart;
+  d.gate = g->gate; d.gate_min = g->gate_min;
+  return d;
+}
+
+__device__ __forceinline__ const double* dg_sel(const DgemmArgs& d, int sel, const double* explicit_ptr, int base) {
   if (sel < 0) return explicit_ptr;
   int i = base + sel;
   i -= (i >= 3) ? 3 : 0;
   i -= (i >= 3) ? 3 : 0;
-  return d.ring[i];
+  // prvalues (unary +): `c ? d.ring0 : d.ring1` on lvalues selects between ADDRESSES inside the struct, which is the
+  // run-time indexing again
+  const double* r0 = +d.ring0; const double* r1 = +d.ring1; const double* r2 = +d.ring2;
+  return i == 0 ? +r0 : (i == 1 ? +r1 : +r2);
 }
 
 #ifdef TADMM_DGEMM_STAMPS
@@ -46,7 +75,7 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const DgemmDesc* __restrict_
   __shared__ double red[4][4][64 * 4];   // [wave][tile][lane*4+reg]  32 KB
   __shared__ double rowred[32][33];
   const BlockRef br = map[blockIdx.x];
-  const DgemmDesc d = descs[br.prob];
+  const DgemmArgs d = dg_args(descs + br.prob);
   if (d.gate && *d.gate < d.gate_min) return;
   const int base = d.rot ? *d.rot : 0;
   const double* __restrict__ A = dg_sel(d, d.selA, d.A, base);
@@ -208,7 +237,7 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   __shared__ __attribute__((aligned(16))) double smem[2 * kBuf > kDT * (TN + 1) ? 2 * kBuf : kDT * (TN + 1)];
   __shared__ double rowred[kDT][4];
   const BlockRef br = map[blockIdx.x];
-  const DgemmDesc d = descs[br.prob];
+  const DgemmArgs d = dg_args(descs + br.prob);
   if (d.gate && *d.gate < d.gate_min) return;
   const int base = d.rot ? *d.rot : 0;
   const G<const double>* __restrict__ A = gp(dg_sel(d, d.selA, d.A, base));
@@ -412,7 +441,7 @@ void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int 
 // Y <- s0*T + s1*Qb  (first Chebyshev step of a stage, in place of T); ring-addressed, gated like the products.
 __global__ __launch_bounds__(256) void daxpby_kernel(const DgemmDesc* __restrict__ descs, const BlockRef* __restrict__ map) {
   const BlockRef br = map[blockIdx.x];
-  const DgemmDesc d = descs[br.prob];
+  const DgemmArgs d = dg_args(descs + br.prob);
   if (d.gate && *d.gate < d.gate_min) return;
   const int base = d.rot ? *d.rot : 0;
   double* __restrict__ C = const_cast<double*>(dg_sel(d, d.selC, d.C, base));

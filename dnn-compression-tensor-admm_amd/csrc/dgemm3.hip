@@ -39,7 +39,10 @@ __device__ __forceinline__ const double* ring_sel(const DgemmDesc& d, int sel, c
   int i = base + sel;
   i -= (i >= 3) ? 3 : 0;
   i -= (i >= 3) ? 3 : 0;
-  return i == 0 ? d.ring[0] : (i == 1 ? d.ring[1] : d.ring[2]);      // no runtime index: it would move d to scratch
+  // no runtime index, and prvalues: `c ? d.ring[0] : d.ring[1]` on lvalues selects between ADDRESSES inside the by-value
+  // descriptor, which is a run-time index again and moves the whole copy to scratch
+  const double* r0 = +d.ring[0]; const double* r1 = +d.ring[1]; const double* r2 = +d.ring[2];
+  return i == 0 ? +r0 : (i == 1 ? +r1 : +r2);
 }
 
 // (x, y) -> three packed bf16 pairs with x = sum of the planes exactly (v_cvt_pk_bf16_f32, round to nearest even)
