@@ -212,15 +212,12 @@ __device__ __forceinline__ double pair_inner_solve_fast(const PairScratch& S, in
       const int ew = __builtin_amdgcn_frexp_exp(wd);
       const int ex = zd == 0.0 ? ew : max(__builtin_amdgcn_frexp_exp(zd), ew);
       const float zf = (float)__builtin_amdgcn_ldexp(zd, -ex), wf = (float)__builtin_amdgcn_ldexp(wd, -ex);
-      const float az = fabsf(zf), aw = fabsf(wf);
-      float tf;
-      if (az >= aw) {
-        const float u = wf * __builtin_amdgcn_rcpf(az);
-        tf = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(1.0f + u * u));
-      } else {
-        const float v = az * __builtin_amdgcn_rcpf(aw);
-        tf = copysignf(__builtin_amdgcn_rcpf(v + __builtin_amdgcn_sqrtf(1.0f + v * v)), wf);
-      }
+      // tan of the rotation angle, t = sign(z) w / (|z| + sqrt(z^2 + w^2)): after the scaling the larger of |z|, |w| lies in
+      // [0.5, 1), so the sum of squares neither overflows nor underflows and ONE branch-free expression serves both
+      // regimes (the |z| >= |w| / |z| < |w| pair it replaces executed both of its sides whenever the eight-lane groups of
+      // a wave disagreed: a reciprocal, a square root and a reciprocal each)
+      const float az = fabsf(zf);
+      float tf = wf * __builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(__builtin_fmaf(az, az, wf * wf)));
       if (zf < 0.0f) tf = -tf;
       t = (double)tf;
       const double x = 1.0 + t * t;
