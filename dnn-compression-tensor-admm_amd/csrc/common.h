@@ -75,6 +75,9 @@ struct EigDesc {
   double* evec_out;   // optional: [r][N] eigenvectors as rows in fp64 (tadmm_eigh_f64), nullable
   double* sblk;       // [Npad/16][16*16] carried self-Gram of every 16-column super-block (tick3), nullable
   int32_t ldo;        // leading dimension of out_a (0: r)
+  int32_t period;     // ticks per sweep of the GROUP's schedule (tick3 groups; 0: this problem's own players - 1): with one
+                      // period for every problem of a group all sweeps start at the same tick, so the self pass is launched
+                      // once per global sweep; a problem with fewer players idles in the ticks beyond its own
 };
 void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr,
                         double* prev_dev = nullptr);   // prev_dev: [nprob] history of jacobi_conv_kernel, reset here

@@ -183,6 +183,12 @@ static inline int choose_jacobi_mode(int ld_max) {
   return want;
 }
 
+// One sweep period for every problem of a tick3 group (EigDesc::period); TADMM_JACOBI_ALIGN=0 restores per-problem periods.
+static inline bool align_sweeps_on() {
+  static const bool on = !(getenv("TADMM_JACOBI_ALIGN") && !atoi(getenv("TADMM_JACOBI_ALIGN")));
+  return on;
+}
+
 // Pinned verdict slots + events of the pipelined convergence poll (one per plan).
 struct PollCtx {
   hipEvent_t ev[2];
@@ -219,6 +225,7 @@ struct EigGroup {
   const int32_t* skip = nullptr;    // optional per-problem predicate (non-zero: the problem is dropped)
   int npad_max = 0;                 // largest padded problem size (<= 64: single-launch solver)
   int expected = 0;                 // sweeps the previous run of this group needed (0: unknown)
+  bool aligned = false;             // every EigDesc carries period = gsteps: all sweeps start at the same tick
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
 };
@@ -267,7 +274,7 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
       if (g.mode >= 2) {
         bool any_first = false;     // does any unfinished problem start a sweep of its own at this tick?
         for (int q = 0; q < g.neig && !any_first; ++q)
-          any_first = !known_done[q] && g.players[q] > 1 && (tick % (g.players[q] - 1)) == 0;
+          any_first = !known_done[q] && g.players[q] > 1 && (tick % (g.aligned ? g.gsteps : g.players[q] - 1)) == 0;
         if (any_first) launch_jacobi_self(g.ed, g.self_map, g.self_blocks, tick, tol, inner_sweeps, g.ld_max, s);
         launch_jacobi_tick3(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
       } else {

@@ -329,8 +329,9 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
   if (*d.done) return;
   const int nb = self_mode ? (d.nb >> 1) : d.nb;
   const int steps = nb - 1;
-  const int sweep = tick / steps;
-  const int step = tick - sweep * steps;
+  const int period = (self_mode && d.period > 0) ? d.period : steps;
+  const int sweep = tick / period;
+  const int step = tick - sweep * period;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (step == 0 && sweep > 0) {
     if (d.off[(sweep - 1) & 1] < tol) {           // previous sweep saw nothing left to rotate
@@ -690,8 +691,10 @@ __global__ __launch_bounds__(512) void jacobi_tick3_kernel(const EigDesc* __rest
   const EigDesc d = descs[br.prob];
   const int nbs = d.nb >> 1;
   const int steps = nbs - 1;
-  const int sweep = tick / steps;
-  const int step = tick - sweep * steps;
+  const int period = d.period > 0 ? d.period : steps;
+  const int sweep = tick / period;
+  const int step = tick - sweep * period;
+  if (step >= steps) return;                     // idle tick of the group's schedule (this problem has fewer players)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = wave >> 2, wv = wave & 3, th = tid & 255;
   const int ld = d.ld, ldp = ld + 2;
@@ -1116,7 +1119,8 @@ __global__ __launch_bounds__(256) void jacobi_conv_kernel(const EigDesc* __restr
   for (int q = threadIdx.x; q < nprob; q += 256) {
     const EigDesc d = descs[q];
     if (*d.done) { verdict[1 + q] = 1; continue; }
-    const int steps = (super ? (d.nb >> 1) : d.nb) - 1;
+    const int own = (super ? (d.nb >> 1) : d.nb) - 1;
+    const int steps = (own > 0 && d.period > 0) ? d.period : own;
     bool conv = false;
     if (steps > 0 && tick % steps == 0) {
       const int swp = tick / steps - 1;

@@ -523,8 +523,10 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       ph.nblocks = (int)map.size();
       if (img && !map.empty()) img->put(ph.map_off, map.data(), map.size() * sizeof(BlockRef));
     };
+    const bool align_sweeps = align_sweeps_on();
     {
       EigMaps m = build_maps(ed);
+      if (m.mode >= 2 && align_sweeps) for (EigDesc& e : ed) e.period = m.gsteps;
       sp.mode = m.mode; sp.super = m.mode >= 1; sp.tick_lds = m.tick_lds; sp.gsteps = m.gsteps;
       sp.ld_max = m.ld_max; sp.npad_max = m.npad_max; sp.nb = m.nb;
       place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m.tick);
@@ -535,6 +537,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     }
     {
       EigMaps m = build_maps(ed_fb);
+      if (m.mode >= 2 && align_sweeps) for (EigDesc& e : ed_fb) e.period = m.gsteps;
       StepPlan::Fallback& fb = sp.fb;
       fb.neig = (int)ed_fb.size();
       fb.mode = m.mode; fb.tick_lds = m.tick_lds; fb.gsteps = m.gsteps; fb.ld_max = m.ld_max; fb.npad_max = m.npad_max;
@@ -1021,7 +1024,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
     const int32_t* skip = filtered ? (const int32_t*)D(sp.skip_off) : nullptr;
     EigGroup eg;
-    eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode;
+    eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode; eg.aligned = sp.mode >= 2 && align_sweeps_on();
     eg.ld_max = sp.ld_max; eg.tick_lds = sp.tick_lds;
     eg.tick_map = (const BlockRef*)D(sp.eig_tick.map_off); eg.tick_blocks = sp.eig_tick.nblocks;
     eg.self_map = (const BlockRef*)D(sp.eig_self.map_off); eg.self_blocks = sp.eig_self.nblocks;
@@ -1059,7 +1062,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
         const EigDesc* fd = (const EigDesc*)D(fb.tick.desc_off);
         const int32_t* fskip = (const int32_t*)D(sp.fb_skip_off);
         EigGroup fgp;
-        fgp.ed = fd; fgp.neig = fb.neig; fgp.players = fb.nb.data(); fgp.gsteps = fb.gsteps; fgp.mode = fb.mode;
+        fgp.ed = fd; fgp.neig = fb.neig; fgp.players = fb.nb.data(); fgp.gsteps = fb.gsteps; fgp.mode = fb.mode; fgp.aligned = fb.mode >= 2 && align_sweeps_on();
         fgp.ld_max = fb.ld_max; fgp.tick_lds = fb.tick_lds;
         fgp.tick_map = (const BlockRef*)D(fb.tick.map_off); fgp.tick_blocks = fb.tick.nblocks;
         fgp.self_map = (const BlockRef*)D(fb.self.map_off); fgp.self_blocks = fb.self.nblocks;
