@@ -428,7 +428,9 @@ void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int 
     fprintf(stderr, "\n");
   }
 #endif
-  static const int kw = getenv("TADMM_DGEMM_KW") ? atoi(getenv("TADMM_DGEMM_KW")) : 1;      // 2: eight-wave variant (A/B)
+  // eight waves (two K halves) by default: two waves per SIMD issue fp64 MFMAs at 45 instead of 33-35 TF/s chip-wide
+  // (scripts/micro/mfma_f64_peak.hip); worth 1.6 % of the ResNet-50 iteration, neutral elsewhere.  TADMM_DGEMM_KW=1: four.
+  static const int kw = getenv("TADMM_DGEMM_KW") ? atoi(getenv("TADMM_DGEMM_KW")) : 2;
   if (tile_n == 32) {
     if (kw == 2) hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 2>), dim3(nblocks), dim3(512), 0, s, descs_dev, map_dev);
     else hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 1>), dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);
