@@ -292,7 +292,7 @@ def main():
             traffic = pm.get("dgemm_nt_tile_kernel", {}).get("hbm_bytes_per_launch_corrected") \
                 if args.config == "resnet50_tt" and world == 1 else None
             out["roofline"] = {
-                "bound": "mfma", "kernel": "dgemm_nt_tile_kernel<32,1> (fp64 MFMA 16x16x4: block products of the "
+                "bound": "mfma", "kernel": "dgemm_nt_tile_kernel<32,2> (fp64 MFMA 16x16x4, 64x32 tiles, eight waves: block products of the "
                                            "filtered eigen-solver)",
                 "achieved": gemm_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F64_MFMA_TFLOPS,
                 "peak_measured": PEAK_F64_MFMA_MEASURED_TFLOPS, "frac_of_measured": gemm_tf / PEAK_F64_MFMA_MEASURED_TFLOPS,
@@ -303,8 +303,8 @@ def main():
                 "time_share": (ft["gemm_ms"] / reps) / max(1e-9, total_ms),
                 "flops_per_step": ft["gemm_flops"] / reps,
                 "note": "dominant kernel by time.  peak = vendor fp64 matrix figure; peak_measured = what v_mfma_f64_16x16x4 "
-                        "sustains here with register operands (scripts/micro/mfma_f64_peak.hip; 33-35 TF/s at this "
-                        "kernel's one wave per SIMD).  achieved = 2*M*N*K of every product the launches executed "
+                        "sustains here with register operands at two waves per SIMD (scripts/micro/mfma_f64_peak.hip; 33-35 TF/s at "
+                        "one wave per SIMD).  achieved = 2*M*N*K of every product the launches executed "
                         "(gated-off problems excluded; read back from the device) / their HIP-event time, each launch "
                         "timed on the launch stream.  These FLOPs are the work of the filter, not part of the "
                         "thin-SVD model"}
