@@ -267,6 +267,7 @@ def main():
         # dominant kernel (adds syncs, so it is separate from the timed region above)
         plan.enable_timing(True)
         acc, ft = None, dict(gemm_ms=0.0, gemm_launches=0, gemm_flops=0.0)
+        jt = dict(tick_ms=0.0, tick_launches=0, tick_flops=0.0, tick_wgs=0.0)
         reps = max(3, min(args.steps, 10))
         for _ in range(reps):
             plan.run(update_u=True)
@@ -274,6 +275,8 @@ def main():
             f = plan.filter_timing()
             acc = t if acc is None else {k: acc[k] + t[k] for k in t}
             ft = {k: ft[k] + f[k] for k in ft}
+            j = plan.jacobi_timing()
+            jt = {k: jt[k] + j[k] for k in jt}
         ph = {k: v / reps for k, v in acc.items()}
         plan.enable_timing(False)
         fstats = plan.filter_stats()
@@ -287,11 +290,35 @@ def main():
         except Exception:
             pass
         total_ms = sum(v for k, v in ph.items() if k.endswith("_ms"))
+        roof_tick = None
+        if jt["tick_launches"] > 0 and jt["tick_ms"] > 0:
+            tick_tf = jt["tick_flops"] / (jt["tick_ms"] * 1e-3) / 1e12
+            ttraffic = pm.get("jacobi_tick3_kernel", {}).get("hbm_bytes_per_launch_corrected") \
+                if args.config == "resnet50_tt" and world == 1 else None
+            roof_tick = {
+                "bound": "mfma", "kernel": "jacobi_tick3_kernel (block-Jacobi tournament of the Rayleigh-Ritz and full eigen-solves: "
+                                           "fp64 MFMA Gram / column updates around two serial 16x16 rotation solves)",
+                "achieved": tick_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tick_tf / PEAK_F64_MFMA_TFLOPS,
+                "peak_measured": PEAK_F64_MFMA_MEASURED_TFLOPS, "frac_of_measured": tick_tf / PEAK_F64_MFMA_MEASURED_TFLOPS,
+                "traffic": ttraffic,
+                "traffic_source": "profiles/r02_pmc_traffic.json (per launch)" if ttraffic else None,
+                "launches_per_step": jt["tick_launches"] / reps,
+                "avg_launch_us": 1e3 * jt["tick_ms"] / jt["tick_launches"],
+                "workgroups_per_launch": jt["tick_wgs"] / jt["tick_launches"],
+                "time_share": (jt["tick_ms"] / reps) / max(1e-9, total_ms),
+                "flops_per_step": jt["tick_flops"] / reps,
+                "note": "achieved = matrix-core flops the launches executed (2560 x row length per workgroup: cross Gram and two "
+                        "rounds of column updates of a 32-column pair) / their HIP-event time, each launch timed on the launch "
+                        "stream.  The kernel is latency-bound, not throughput-bound: a launch has 20-110 workgroups on 256 CUs "
+                        "and 7.6 of its 14 us are two serial 16x16 rotation solves on one wave each (DESIGN.md 5, "
+                        "scripts/stamp_jacobi.sh), so the fraction of the matrix peak says how little of the chip one "
+                        "dependent chain can use, not how well the tile is written"}
+        roof_gemm = None
         if ft["gemm_launches"] > 0 and ft["gemm_ms"] > 0:
             gemm_tf = ft["gemm_flops"] / (ft["gemm_ms"] * 1e-3) / 1e12
             traffic = pm.get("dgemm_nt_tile_kernel", {}).get("hbm_bytes_per_launch_corrected") \
                 if args.config == "resnet50_tt" and world == 1 else None
-            out["roofline"] = {
+            roof_gemm = {
                 "bound": "mfma", "kernel": "dgemm_nt_tile_kernel<32,2> (fp64 MFMA 16x16x4, 64x32 tiles, eight waves: block products of the "
                                            "filtered eigen-solver)",
                 "achieved": gemm_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F64_MFMA_TFLOPS,
@@ -302,12 +329,18 @@ def main():
                 "avg_launch_us": 1e3 * ft["gemm_ms"] / ft["gemm_launches"],
                 "time_share": (ft["gemm_ms"] / reps) / max(1e-9, total_ms),
                 "flops_per_step": ft["gemm_flops"] / reps,
-                "note": "dominant kernel by time.  peak = vendor fp64 matrix figure; peak_measured = what v_mfma_f64_16x16x4 "
+                "note": "peak = vendor fp64 matrix figure; peak_measured = what v_mfma_f64_16x16x4 "
                         "sustains here with register operands at two waves per SIMD (scripts/micro/mfma_f64_peak.hip; 33-35 TF/s at "
                         "one wave per SIMD).  achieved = 2*M*N*K of every product the launches executed "
                         "(gated-off problems excluded; read back from the device) / their HIP-event time, each launch "
                         "timed on the launch stream.  These FLOPs are the work of the filter, not part of the "
                         "thin-SVD model"}
+        # `roofline` = whichever of the two kernels took more time in THIS run; the other one stays beside it
+        cands = [r for r in (roof_gemm, roof_tick) if r]
+        cands.sort(key=lambda r: -r["time_share"])
+        if cands:
+            out["roofline"] = dict(cands[0], dominant_by="summed HIP-event time of its launches in the instrumented pass")
+        roof_second = cands[1] if len(cands) > 1 else None
         gemm_ms = ph["project_ms"] + ph["reconstruct_ms"]
         sweep_ms = ph["unfold_ms"] + ph["fold_update_ms"]
         out["phases_ms"] = ph
@@ -324,6 +357,7 @@ def main():
                               "peak_tflops": PEAK_F32_MFMA_TFLOPS},
             "hbm_sweeps": {"achieved_gbs": my_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0,
                            "peak_gbs": PEAK_HBM_GBS, "algorithmic_bytes": my_bytes},
+            "second_kernel": roof_second,
             "eig_time_share": ph["eig_ms"] / max(1e-9, total_ms),
             # the whole eigen phase (filter + Rayleigh-Ritz Jacobi + fallbacks) against the fp64 matrix peak, with the
             # implementation-independent 8*N^3 model of a full symmetric eigen-decomposition

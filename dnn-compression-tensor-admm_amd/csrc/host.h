@@ -210,6 +210,13 @@ struct PollCtx {
   }
 };
 
+// instrumented runs only (tadmm_plan_enable_timing): every jacobi_tick3 launch timed on its own
+struct JacobiTiming {
+  bool on = false;
+  hipEvent_t a{}, b{};
+  double tick_ms = 0.0; int tick_launches = 0; double tick_flops = 0.0; double tick_wgs = 0.0;
+};
+
 // One grouped eigen-solve: `neig` symmetric problems whose descriptors / block maps already sit on the device.
 struct EigGroup {
   const EigDesc* ed = nullptr;
@@ -226,6 +233,7 @@ struct EigGroup {
   int npad_max = 0;                 // largest padded problem size (<= 64: single-launch solver)
   int expected = 0;                 // sweeps the previous run of this group needed (0: unknown)
   bool aligned = false;             // every EigDesc carries period = gsteps: all sweeps start at the same tick
+  const int* row_len = nullptr;     // per problem: ld of its X image (timing only: executed flops of a tick)
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
 };
@@ -240,7 +248,8 @@ struct EigGroup {
 // Small groups (every problem <= 64 columns) run in ONE launch (jacobi_small_kernel decides convergence itself);
 // *small_pending is set and the caller, after queueing the group's finalize launches, calls check_small_group.
 static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll, double tol, int inner_sweeps,
-                                int max_sweeps, bool debug, hipStream_t s, int* sweeps_out, bool* small_pending) {
+                                int max_sweeps, bool debug, hipStream_t s, int* sweeps_out, bool* small_pending,
+                                JacobiTiming* jt = nullptr) {
   *sweeps_out = 0;
   *small_pending = false;
   if (g.neig == 0) return TADMM_OK;
@@ -276,7 +285,27 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
         for (int q = 0; q < g.neig && !any_first; ++q)
           any_first = !known_done[q] && g.players[q] > 1 && (tick % (g.aligned ? g.gsteps : g.players[q] - 1)) == 0;
         if (any_first) launch_jacobi_self(g.ed, g.self_map, g.self_blocks, tick, tol, inner_sweeps, g.ld_max, s);
+        const bool timed = jt && jt->on;
+        if (timed) (void)hipEventRecord(jt->a, s);
         launch_jacobi_tick3(g.ed, g.tick_map, g.tick_blocks, tick, tol, g.ld_max, s);
+        if (timed) {
+          float ms = 0.f;
+          (void)hipEventRecord(jt->b, s);
+          (void)hipEventSynchronize(jt->b);
+          (void)hipEventElapsedTime(&ms, jt->a, jt->b);
+          jt->tick_ms += ms; jt->tick_launches += 1;
+          // executed MFMA work of a workgroup (two 16-column super-blocks, rows of length ld): cross Gram 2*16*16*ld, two
+          // rounds of column updates 2 * (2*16*16*ld) each -> 2560*ld; problems the host knows to be finished are left out,
+          // workgroups of a padded schedule's idle ticks too
+          for (int q = 0; q < g.neig; ++q) {
+            if (known_done[q] || g.players[q] < 2) continue;
+            const int own = g.players[q] - 1;
+            if (g.aligned && (tick % g.gsteps) >= own) continue;
+            const double ld = g.row_len ? g.row_len[q] : g.ld_max;
+            jt->tick_flops += 2560.0 * ld * (g.players[q] / 2);
+            jt->tick_wgs += g.players[q] / 2;
+          }
+        }
       } else {
         launch_jacobi_tick(g.ed, g.tick_map, g.tick_blocks, tick, tol, inner_sweeps, g.tick_lds, g.mode == 1, s);
       }

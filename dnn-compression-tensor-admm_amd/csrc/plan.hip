@@ -147,6 +147,7 @@ struct StepPlan {
   size_t off_off = 0, done_off = 0;   // contiguous [neig][3] doubles / [neig] ints
   size_t prev_off_dev = 0;            // [neig] doubles of the convergence kernel
   std::vector<int> nb;            // per problem
+  std::vector<int> row_len;       // per problem: ld of the X image (instrumented runs)
   std::vector<int> layer_of;      // problem -> layer
   // filtered eigen-solver (filter_host.h): the problems of this level it serves keep their slot in the eig group,
   // where their r' x r' Rayleigh-Ritz problem replaces the full N x N one; the full variants form the fallback group
@@ -158,7 +159,7 @@ struct StepPlan {
     Phase tick, self, norm, ext;
     int neig = 0, gsteps = 0, mode = 0, ld_max = 0, npad_max = 0, last_sweeps = 0;
     size_t tick_lds = 0, prev_off_dev = 0;
-    std::vector<int> nb;
+    std::vector<int> nb, row_len;
   } fb;
 };
 
@@ -190,6 +191,7 @@ struct tadmm_plan_s {
   // filtered eigen-solver statistics of the last run
   int filt_problems = 0, filt_fallbacks = 0, filt_stages = 0;
   FilterTiming ftm;
+  JacobiTiming jtm;
   const int32_t* resid_index = nullptr;   // device map local layer -> slot of the caller's residual array (lanes)
   struct Lanes* lanes = nullptr;          // set on a parent plan that runs its layers as two concurrent lanes
 };
@@ -495,7 +497,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
         ed[p] = e;
       }
     }
-    struct EigMaps { std::vector<BlockRef> tick, self, norm, ext; std::vector<int> nb; int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0; size_t tick_lds = 0; };
+    struct EigMaps { std::vector<BlockRef> tick, self, norm, ext; std::vector<int> nb, row_len; int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0; size_t tick_lds = 0; };
     auto build_maps = [&](const std::vector<EigDesc>& descs) {
       EigMaps m;
       for (const EigDesc& e : descs) { m.ld_max = std::max(m.ld_max, e.ld); m.npad_max = std::max(m.npad_max, e.Npad); }
@@ -507,6 +509,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
         const EigDesc& e = descs[pq];
         const int units = super ? e.nb / 2 : e.nb;       // players of the tournament
         m.nb.push_back(units);
+        m.row_len.push_back(e.ld);
         m.gsteps = std::max(m.gsteps, units - 1);
         for (int b = 0; b < units / 2; ++b) m.tick.push_back(BlockRef{pq, b});
         if (m.mode >= 2) for (int b = 0; b < units; ++b) m.self.push_back(BlockRef{pq, b});
@@ -528,7 +531,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       EigMaps m = build_maps(ed);
       if (m.mode >= 2 && align_sweeps) for (EigDesc& e : ed) e.period = m.gsteps;
       sp.mode = m.mode; sp.super = m.mode >= 1; sp.tick_lds = m.tick_lds; sp.gsteps = m.gsteps;
-      sp.ld_max = m.ld_max; sp.npad_max = m.npad_max; sp.nb = m.nb;
+      sp.ld_max = m.ld_max; sp.npad_max = m.npad_max; sp.nb = m.nb; sp.row_len = m.row_len;
       place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m.tick);
       sp.eig_desc_off = sp.eig_tick.desc_off;
       place_map(sp.eig_self, sp.eig_tick, m.self);
@@ -541,7 +544,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       StepPlan::Fallback& fb = sp.fb;
       fb.neig = (int)ed_fb.size();
       fb.mode = m.mode; fb.tick_lds = m.tick_lds; fb.gsteps = m.gsteps; fb.ld_max = m.ld_max; fb.npad_max = m.npad_max;
-      fb.nb = m.nb;
+      fb.nb = m.nb; fb.row_len = m.row_len;
       fb.prev_off_dev = ar.take((size_t)std::max(1, fb.neig) * 8);
       place(fb.tick, ed_fb.data(), ed_fb.size() * sizeof(EigDesc), fb.neig, m.tick);
       place_map(fb.self, fb.tick, m.self);
@@ -991,6 +994,9 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
   p->ftm.gemm_ms = 0.0; p->ftm.gemm_launches = 0; p->ftm.gemm_flops = 0.0;
   p->ftm.fast_ms = 0.0; p->ftm.fast_launches = 0; p->ftm.fast_flops = 0.0;
   if (p->timing) { p->ftm.a = p->ev[14]; p->ftm.b = p->ev[15]; }
+  p->jtm.on = p->timing;
+  p->jtm.tick_ms = 0.0; p->jtm.tick_launches = 0; p->jtm.tick_flops = 0.0; p->jtm.tick_wgs = 0.0;
+  if (p->timing) { p->jtm.a = p->ev[14]; p->jtm.b = p->ev[15]; }
   // timing helper: record a pair of events around a phase and accumulate after a sync
   auto tic = [&](int i) { if (p->timing) (void)hipEventRecord(p->ev[i], s); };
   auto toc = [&](int i, int slot) {
@@ -1024,7 +1030,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
     const EigDesc* ed = (const EigDesc*)D(sp.eig_desc_off);
     const int32_t* skip = filtered ? (const int32_t*)D(sp.skip_off) : nullptr;
     EigGroup eg;
-    eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode; eg.aligned = sp.mode >= 2 && align_sweeps_on();
+    eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode; eg.aligned = sp.mode >= 2 && align_sweeps_on(); eg.row_len = sp.row_len.data();
     eg.ld_max = sp.ld_max; eg.tick_lds = sp.tick_lds;
     eg.tick_map = (const BlockRef*)D(sp.eig_tick.map_off); eg.tick_blocks = sp.eig_tick.nblocks;
     eg.self_map = (const BlockRef*)D(sp.eig_self.map_off); eg.self_blocks = sp.eig_self.nblocks;
@@ -1037,7 +1043,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
     bool small_pending = false;
     {
       const int rc = run_eig_group(h, eg, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &gs,
-                                   &small_pending);
+                                   &small_pending, &p->jtm);
       if (rc != TADMM_OK) return rc;
     }
     sp.last_sweeps = gs;
@@ -1062,7 +1068,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
         const EigDesc* fd = (const EigDesc*)D(fb.tick.desc_off);
         const int32_t* fskip = (const int32_t*)D(sp.fb_skip_off);
         EigGroup fgp;
-        fgp.ed = fd; fgp.neig = fb.neig; fgp.players = fb.nb.data(); fgp.gsteps = fb.gsteps; fgp.mode = fb.mode; fgp.aligned = fb.mode >= 2 && align_sweeps_on();
+        fgp.ed = fd; fgp.neig = fb.neig; fgp.players = fb.nb.data(); fgp.gsteps = fb.gsteps; fgp.mode = fb.mode; fgp.aligned = fb.mode >= 2 && align_sweeps_on(); fgp.row_len = fb.row_len.data();
         fgp.ld_max = fb.ld_max; fgp.tick_lds = fb.tick_lds;
         fgp.tick_map = (const BlockRef*)D(fb.tick.map_off); fgp.tick_blocks = fb.tick.nblocks;
         fgp.self_map = (const BlockRef*)D(fb.self.map_off); fgp.self_blocks = fb.self.nblocks;
@@ -1072,7 +1078,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
         fgp.skip = fskip;
         int fgs = 0;
         bool fsmall = false;
-        rc = run_eig_group(h, fgp, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &fgs, &fsmall);
+        rc = run_eig_group(h, fgp, p->poll, p->tol, p->inner_sweeps, p->max_global_sweeps, p->debug, s, &fgs, &fsmall, &p->jtm);
         if (rc != TADMM_OK) return rc;
         total_sweeps += fgs;
         launch_eig_norms(fd, (const BlockRef*)D(fb.norm.map_off), fb.norm.nblocks, s, fskip);
@@ -1136,6 +1142,19 @@ int tadmm_plan_filter_timing(tadmm_plan p, double out[4]) {
     return TADMM_OK;
   }
   out[0] = p->ftm.gemm_ms; out[1] = p->ftm.gemm_launches; out[2] = p->ftm.gemm_flops; out[3] = 0.0;
+  return TADMM_OK;
+}
+
+int tadmm_plan_jacobi_timing(tadmm_plan p, double out[4]) {
+  if (!p || !out) return TADMM_ERR_INVALID;
+  if (p->lanes) {
+    double a[4], b[4];
+    tadmm_plan_jacobi_timing(p->lanes->sub[0], a);
+    tadmm_plan_jacobi_timing(p->lanes->sub[1], b);
+    for (int i = 0; i < 4; ++i) out[i] = a[i] + b[i];
+    return TADMM_OK;
+  }
+  out[0] = p->jtm.tick_ms; out[1] = p->jtm.tick_launches; out[2] = p->jtm.tick_flops; out[3] = p->jtm.tick_wgs;
   return TADMM_OK;
 }
 

@@ -100,6 +100,7 @@ ABI = {
     "tadmm_plan_filter_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tadmm_plan_filter_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "tadmm_plan_filter_timing_fast": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "tadmm_plan_jacobi_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "tadmm_plan_ranks": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "tadmm_plan_lanes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "tadmm_lane_split": (C.c_int, [C.c_int, C.POINTER(LayerDesc), C.POINTER(C.c_int32)]),

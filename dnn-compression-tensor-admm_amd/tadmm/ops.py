@@ -136,6 +136,12 @@ class ProjectionPlan:
         self.h.check(self.h.lib.tadmm_plan_filter_timing_fast(self._plan, out))
         return dict(ms=float(out[0]), launches=int(out[1]), flops=float(out[2]))
 
+    def jacobi_timing(self) -> dict:
+        """Instrumented runs: summed duration, count, executed matrix-core FLOPs and workgroups of the jacobi_tick3 launches."""
+        out = (C.c_double * 4)()
+        self.h.check(self.h.lib.tadmm_plan_jacobi_timing(self._plan, out))
+        return dict(tick_ms=float(out[0]), tick_launches=int(out[1]), tick_flops=float(out[2]), tick_wgs=float(out[3]))
+
     def singular_values(self, layer: int, step: int) -> np.ndarray:
         r = self.ranks[layer][step + 1]
         out = (C.c_double * r)()

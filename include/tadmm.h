@@ -131,6 +131,11 @@ int tadmm_plan_filter_timing(tadmm_plan p, double out[4]);
  * stage but the last one a level needed in the previous run; TADMM_FILTER_FAST=0 keeps all products in fp64):
  * out[0] = ms, out[1] = launches, out[2] = ALGORITHMIC flops 2*M*N*K (six bf16 products are executed per flop pair). */
 int tadmm_plan_filter_timing_fast(tadmm_plan p, double out[4]);
+/* The same for the launches of jacobi_tick3_kernel (the block-Jacobi tournament of the Rayleigh-Ritz and full solves):
+ * out[0] = ms, out[1] = launches, out[2] = matrix-core flops the launches executed (2560 * row length per workgroup of
+ * a problem the host did not yet know to be finished: cross Gram + two rounds of column updates), out[3] = those
+ * workgroups. */
+int tadmm_plan_jacobi_timing(tadmm_plan p, double out[4]);
 /* clamped ranks of a layer (r_0..r_d); returns d+1 */
 int tadmm_plan_ranks(tadmm_plan p, int layer, int32_t* ranks_out);
 /* Lanes.  A plan whose table mixes long chains of eigen-solves (e.g. the 3x3 kernels of ResNet layer3/layer4) with
