@@ -276,8 +276,8 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
     s.O = g.O; s.I = g.I; s.K2 = g.K2;
     s.numel = g.numel;
     if (g.K2 > 1) {
-      int ich = std::min(g.I, 256);
-      while ((int64_t)g.K2 * (ich + 1) > 12288 && ich > 1) ich /= 2;
+      int ich = std::min(g.I, 512);
+      while ((int64_t)g.K2 * (ich + 4) > 12288 && ich > 1) ich /= 2;
       s.ichunk = ich;
       s.nchunk = (g.I + ich - 1) / ich;
       s.nblk = g.O * s.nchunk;

@@ -228,7 +228,7 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     s.numel = t.numel;
     if (t.K2 > 1) {
       int ich = std::min(t.I, 256);
-      while ((int64_t)t.K2 * (ich + 1) > 12288 && ich > 1) ich /= 2;
+      while ((int64_t)t.K2 * (ich + 4) > 12288 && ich > 1) ich /= 2;
       s.ichunk = ich;
       s.nchunk = (t.I + ich - 1) / ich;
       s.nblk = t.O * s.nchunk;
