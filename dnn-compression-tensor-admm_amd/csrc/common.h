@@ -75,6 +75,9 @@ struct EigDesc {
   double* evec_out;   // optional: [r][N] eigenvectors as rows in fp64 (tadmm_eigh_f64), nullable
   double* sblk;       // [Npad/16][16*16] carried self-Gram of every 16-column super-block (tick3), nullable
   int32_t ldo;        // leading dimension of out_a (0: r)
+  double* warm;       // jacobi_small only, nullable: [Npad][Npad] eigenvectors of this problem's PREVIOUS solve (row j =
+                      // vector of column j); the solve then starts from X = G * V_prev instead of X = G
+  int32_t* warm_ok;   // [1] the image is valid (written by a converged solve whose spectrum allowed normalising every column)
   int32_t period;     // ticks per sweep of the GROUP's schedule (tick3 groups; 0: this problem's own players - 1): with one
                       // period for every problem of a group all sweeps start at the same tick, so the self pass is launched
                       // once per global sweep; a problem with fewer players idles in the ticks beyond its own
@@ -107,8 +110,9 @@ void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int n
 // whole eigen-solve of small problems (Npad <= 64) in one launch, one workgroup per problem; converged flags go to
 // verdict_pinned[1 + p]
 bool jacobi_small_fits(int npad_max);
+// warm: reserve the second LDS image a warm-started problem needs (EigDesc::warm)
 void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, double tol, int max_sweeps,
-                         const int32_t* skip, int* verdict_pinned, hipStream_t s);
+                         const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm = false);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                       const int32_t* skip = nullptr);
 void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr);

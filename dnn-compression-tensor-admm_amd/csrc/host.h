@@ -233,6 +233,7 @@ struct EigGroup {
   int npad_max = 0;                 // largest padded problem size (<= 64: single-launch solver)
   int expected = 0;                 // sweeps the previous run of this group needed (0: unknown)
   bool aligned = false;             // every EigDesc carries period = gsteps: all sweeps start at the same tick
+  bool warm = false;                // some EigDesc of the group carries a warm-start image (jacobi_small: second LDS image)
   const int* row_len = nullptr;     // per problem: ld of its X image (timing only: executed flops of a tick)
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
@@ -256,7 +257,7 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
   {
     const char* e = getenv("TADMM_JACOBI_SMALL");     // 0: always use the tick kernels (A/B measurements)
     if (g.npad_max > 0 && jacobi_small_fits(g.npad_max) && !(e && !atoi(e))) {
-      launch_jacobi_small(g.ed, g.neig, g.npad_max, tol, std::max(max_sweeps, 60), g.skip, poll.host, s);
+      launch_jacobi_small(g.ed, g.neig, g.npad_max, tol, std::max(max_sweeps, 60), g.skip, poll.host, s, g.warm);
       HIP_OK(h, hipEventRecord(poll.ev[0], s));
       *small_pending = true;
       return TADMM_OK;

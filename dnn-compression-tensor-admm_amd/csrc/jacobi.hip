@@ -931,6 +931,31 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(const EigDesc* __rest
   const double g0 = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
   const double hmax = g0 * g0;
   __syncthreads();
+  // Warm start (HOOI: the same mode's Gram changes little from one sweep to the next).  One-sided Jacobi on X = G V0 with
+  // V0 the eigenvectors of the previous solve ends in G V0 V = G (V0 V): the same eigenpairs, but X starts out with
+  // nearly orthogonal columns and the solve is in its quadratic phase from the first sweep.  X0 = G V0 is formed here
+  // in LDS (row j of X0 = sum_k V0[j][k] * row k of G; G is symmetric), into the second image behind the scratch.
+  if (d.warm && *d.warm_ok) {
+    double* X0 = red + 16;                                             // [Npad][ldp]
+    const int j = tid >> 2, per = Npad >> 2, i0 = (tid & 3) * per;     // per = 8 (Npad 32) or 16 (Npad 64)
+    if (j < Npad) {
+      double acc[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+      const double* __restrict__ vj = d.warm + (int64_t)j * Npad;
+      for (int k = 0; k < Npad; ++k) {
+        const double a = vj[k];
+        const double* g = Xs + k * ldp + i0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < per) acc[c] += a * g[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < per) X0[j * ldp + i0 + c] = acc[c];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Npad * ldp; idx += 256) Xs[idx] = X0[idx];
+    __syncthreads();
+  }
   const int r = lane & 15, q = lane >> 4;
   double prev_m = 0.0, m = 1.0;
   bool conv = false;
@@ -981,6 +1006,30 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(const EigDesc* __rest
           *reinterpret_cast<const double2_t*>(Xs + row * ldp + 2 * c2);
     }
   }
+  if (d.warm) {
+    // eigenvectors for the next solve of this problem: the normalised columns of the converged X.  One-sided Jacobi leaves
+    // them orthogonal to ~tol RELATIVE to their own norms, so small columns are as good as large ones until rounding takes
+    // over (column norm below 1e-8 of the largest): then, or without convergence, the next solve starts cold.
+    __shared__ int warm_bad;
+    if (tid == 0) warm_bad = conv ? 0 : 1;
+    __syncthreads();
+    const double floor2 = 1e-16 * hmax;
+    for (int jrow = wave; jrow < Npad; jrow += 4) {
+      const double* row = Xs + jrow * ldp;
+      double s = 0.0;
+      for (int i = lane; i < Npad; i += 64) s += row[i] * row[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      double inv = 0.0;
+      if (jrow < d.N) {
+        if (s > floor2 && s > 0.0) inv = 1.0 / sqrt(s);
+        else if (lane == 0) warm_bad = 1;
+      }
+      for (int i = lane; i < Npad; i += 64) d.warm[(int64_t)jrow * Npad + i] = row[i] * inv;
+    }
+    __syncthreads();
+    if (tid == 0) *d.warm_ok = warm_bad ? 0 : 1;
+  }
   if (tid == 0) {
     *d.done = conv ? 1 : 0;
     d.off[0] = m; d.off[1] = (double)sweep; d.off[2] = hmax;
@@ -991,9 +1040,21 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(const EigDesc* __rest
 bool jacobi_small_fits(int npad_max) { return npad_max <= kSmallNpad; }
 
 void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, double tol, int max_sweeps,
-                         const int32_t* skip, int* verdict_pinned, hipStream_t s) {
+                         const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm) {
   if (nprob <= 0) return;
-  const size_t lds = ((size_t)npad_max * (npad_max + 2) + 4 * kSmallWaveScratch + 8 + 4) * 8;
+  // X image | 4 wave scratches | red[8] + flags (8 doubles) | second image (warm start only)
+  const size_t lds = ((size_t)npad_max * (npad_max + 2) * (warm ? 2 : 1) + 4 * kSmallWaveScratch + 16) * 8;
+  if (lds > 64 * 1024) {                     // two images of a 64-column problem: above the default dynamic-LDS cap
+    static bool attr_done[64] = {false};     // per device: the attribute belongs to the device's code object
+    int devi = 0;
+    (void)hipGetDevice(&devi);
+    if (!attr_done[devi & 63]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_small_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipGetLastError();
+      attr_done[devi & 63] = true;
+    }
+  }
   hipLaunchKernelGGL(jacobi_small_kernel, dim3(nprob), dim3(256), lds, s, descs_dev, skip, tol, max_sweeps,
                      verdict_pinned);
 }

@@ -70,6 +70,7 @@ struct Lsv {     // one grouped "leading singular vectors" phase over all layers
   size_t eig_desc_off = 0;
   std::vector<int> players;
   int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0;
+  bool warm = false;              // some problem of the group has a warm-start image
   size_t tick_lds = 0;
 };
 
@@ -77,6 +78,7 @@ struct TLayer {
   int O = 0, I = 0, K2 = 1, ro = 0, ri = 0;
   int64_t numel = 0;
   size_t T = 0, P = 0, C = 0, Uo = 0, Ui = 0, Vs = 0, XT = 0, lam = 0, order = 0, sigma = 0, sblk = 0, gpart = 0;
+  size_t warm[2] = {0, 0};        // eigenvectors of the previous HOOI solve of modes 0 / 1 (problems of <= 64 columns)
   int reff[4] = {0, 0, 0, 0};   // vectors each of the four singular-vector requests can deliver
 };
 
@@ -136,6 +138,7 @@ struct tadmm_tucker_plan_s {
   Group gemm[5];         // 0: P = T x1 U_in, 1: P = T x0 U_out, 2: C, 3: Z' = C x1 U_in, 4: Zmat = Z' x0 U_out
   Group unfold, fold;
   size_t sweep_desc_off = 0, resid_partial_off = 0, fac_begin = 0, fac_end = 0;
+  size_t warm_ok_off = 0;
   size_t off_off = 0, done_off = 0, prev_off = 0, skip_off = 0, nT_off = 0, nC_off = 0, err_off = 0, iters_off = 0,
          tol_off = 0, ptrT_off = 0, ptrC_off = 0, numT_off = 0, numC_off = 0;
   PollCtx poll;          // Jacobi verdicts
@@ -147,6 +150,12 @@ struct tadmm_tucker_plan_s {
 };
 
 // Lays the plan out in `base` (nullptr: sizes only).  `img` receives the host copy of the descriptor region.
+// HOOI solves of a mode start from the eigenvectors of that mode's previous solve (TADMM_TUCKER_WARM=0: always cold)
+static bool warm_start_on() {
+  static const bool on = !(getenv("TADMM_TUCKER_WARM") && !atoi(getenv("TADMM_TUCKER_WARM")));
+  return on;
+}
+
 static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const* W, float* const* U, float* const* Z,
                          std::vector<char>* img, size_t desc_region, size_t* desc_bytes, size_t* total_bytes) {
   tadmm_handle h = P->h;
@@ -204,11 +213,16 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     t.sigma = ar.take(npad * 8);
     t.order = ar.take(npad * 4);
     t.sblk = ar.take((npad / 16) * 256 * 8);
+    for (int k = 0; k < 2; ++k) {
+      const int np = og[(2 + k) * n + l].Npad;
+      t.warm[k] = jacobi_small_fits(np) ? ar.take((size_t)np * np * 8) : 0;
+    }
   }
   P->off_off = ar.take((size_t)n * 3 * 8);
   P->done_off = ar.take((size_t)n * 4);
   P->prev_off = ar.take((size_t)n * 8);
   P->skip_off = ar.take((size_t)n * 4);
+  P->warm_ok_off = ar.take((size_t)n * 2 * 4);
   P->nT_off = ar.take((size_t)n * 8);
   P->nC_off = ar.take((size_t)n * 8);
   P->err_off = ar.take((size_t)n * 2 * 8);
@@ -278,6 +292,7 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     v.players.assign(n, 0);
     v.ld_max = 0;
     v.npad_max = 0;
+    v.warm = false;
     for (int l = 0; l < n; ++l) {
       v.ld_max = std::max(v.ld_max, og[k * n + l].ld);
       v.npad_max = std::max(v.npad_max, og[k * n + l].Npad);
@@ -311,6 +326,11 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
       e.done = (int32_t*)dev(P->done_off) + l;
       e.lam = (double*)dev(t.lam); e.order = (int32_t*)dev(t.order); e.sigma = (double*)dev(t.sigma);
       e.r = g.r_eff; e.sblk = (double*)dev(t.sblk);
+      if (k >= 2 && t.warm[k - 2] && warm_start_on()) {
+        e.warm = (double*)dev(t.warm[k - 2]);
+        e.warm_ok = (int32_t*)dev(P->warm_ok_off) + 2 * l + (k - 2);
+        v.warm = true;
+      }
       if (direct) { e.mode = 0; e.out_a = factor; e.ldo = r_full; }
       else { e.mode = 3; e.out_a = (float*)dev(t.Vs); e.ldo = 0; }
       const int units = v.mode >= 1 ? g.nb / 2 : g.nb;
@@ -489,6 +509,7 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     eg.off_dev = (const double*)D(p->off_off); eg.done_dev = (const int*)D(p->done_off);
     eg.skip = sk;
     eg.npad_max = v.npad_max;
+    eg.warm = v.warm;
     int gs = 0;
     bool small_pending = false;
     const int rc = run_eig_group(h, eg, p->poll, p->jtol, p->inner, p->max_sweeps, p->debug, s, &gs, &small_pending);
@@ -505,6 +526,7 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
   };
 
   HIP_OK(h, hipMemsetAsync(skip, 0, (size_t)n * 4, s));
+  HIP_OK(h, hipMemsetAsync(D(p->warm_ok_off), 0, (size_t)n * 2 * 4, s));     // a new tensor: every HOOI solve starts cold once
   HIP_OK(h, hipMemsetAsync(D(p->err_off), 0, (size_t)n * 16, s));
   HIP_OK(h, hipMemsetAsync(D(p->iters_off), 0, (size_t)n * 4, s));
   // factors carry zero columns beyond the number of singular values of their unfolding (never written)

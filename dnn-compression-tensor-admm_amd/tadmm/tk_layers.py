@@ -262,7 +262,7 @@ class _TKLinearBase(nn.Module):
         self.core_tensor = _empty(self.out_rank, self.in_rank)
         self.last_factor = _empty(self.out_features, self.out_rank)
         if bias:
-            self.bias = _empty(self.out_features)
+            self.bias = nn.Parameter(torch.zeros(self.out_features))   # reference: uninitialised (TKLinear.py); see tt_layers._zero_bias
             if dense_b is not None:
                 self.bias.data = dense_b
         else:

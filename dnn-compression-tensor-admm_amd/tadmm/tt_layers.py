@@ -53,6 +53,14 @@ def _empty(*shape):
     return nn.Parameter(torch.empty(*shape))
 
 
+def _zero_bias(n: int):
+    """Deliberate deviation: the reference allocates the bias with `torch.Tensor(n)` (TTLinear.py:53, TTConv.py:254) and
+    the M variants (and every layer built from `dense_w` without `dense_b`) never initialise it -- it holds whatever the
+    allocator hands out, NaNs included.  Zeros are one of the values that memory can hold; `reset_parameters` of the R
+    variants overwrites them as the reference does."""
+    return nn.Parameter(torch.zeros(n))
+
+
 def _decompose(dense_w: Tensor, tt_shapes, tt_ranks, kind):
     """Device TT-SVD of a dense weight (TTConv.py:96-100, TTLinear.py:61-63).  Clamps `tt_ranks` in place
     like ttd.ten2tt does."""
@@ -239,7 +247,7 @@ class TTConv2dR(_TTConvBase):
         self.in_tt_cores = nn.ParameterList(
             [_empty(self.in_tt_ranks[i], self.in_tt_shapes[i], self.in_tt_ranks[i + 1]) for i in range(self.in_tt_order)])
         if bias:
-            self.bias = _empty(self.out_channels)
+            self.bias = _zero_bias(self.out_channels)
             if dense_b is not None:
                 self.bias.data = dense_b
         else:
@@ -299,7 +307,7 @@ class _TTLinearBase(nn.Module):
         self.tt_cores = nn.ParameterList(
             [_empty(self.tt_ranks[i], self.tt_shapes[i], self.tt_ranks[i + 1]) for i in range(self.tt_order)])
         if bias:
-            self.bias = _empty(self.out_features)
+            self.bias = _zero_bias(self.out_features)
             if dense_b is not None:
                 self.bias.data = dense_b
         else:
