@@ -151,9 +151,9 @@ struct tadmm_tucker_plan_s {
 
 // Lays the plan out in `base` (nullptr: sizes only).  `img` receives the host copy of the descriptor region.
 // HOOI solves of a mode start from the eigenvectors of that mode's previous solve (TADMM_TUCKER_WARM=0: always cold)
-static bool warm_start_on() {
-  static const bool on = !(getenv("TADMM_TUCKER_WARM") && !atoi(getenv("TADMM_TUCKER_WARM")));
-  return on;
+static bool warm_start_on() {      // read at every plan creation (tests switch it inside one process)
+  const char* e = getenv("TADMM_TUCKER_WARM");
+  return !(e && !atoi(e));
 }
 
 static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const* W, float* const* U, float* const* Z,

@@ -225,6 +225,38 @@ def test_hooi_error_history_is_non_increasing(dev):
         assert len(errs) == len(hist) and abs(errs[-1] - hist[-1]) <= 1e-6
 
 
+def test_hooi_warm_started_jacobi_equals_cold(dev, monkeypatch):
+    """HOOI solves of a mode start from the previous sweep's eigenvectors (EigDesc::warm): same projection, same sweep
+    counts and errors as with cold starts (TADMM_TUCKER_WARM=0), on layers of <= 64 channels and a run repeated on the
+    same plan (the warm images must be invalidated between runs)."""
+    from tadmm import ops
+    rng = np.random.default_rng(11)
+    shapes = [((64, 64, 3, 3), [25, 23]), ((32, 16, 3, 3), [12, 9]), ((48, 40), [10, 12]), ((16, 16, 3, 3), [16, 16])]
+
+    def run(flag):
+        monkeypatch.setenv("TADMM_TUCKER_WARM", flag)
+        layers = []
+        for i, (shape, ranks) in enumerate(shapes):
+            w = torch.from_numpy((np.random.default_rng(100 + i).standard_normal(shape) * 0.1).astype(np.float32)).to(dev)
+            layers.append(dict(W=w, U=torch.zeros_like(w), Z=torch.zeros_like(w), ranks=ranks))
+        plan = ops.TuckerPlan(layers)
+        out = []
+        for _ in range(2):                       # second run: U has changed, the plan is the same
+            plan.run(update_u=True)
+            torch.cuda.synchronize()
+            out.append(([L["Z"].clone() for L in layers], plan.iterations()))
+        plan.close()
+        return out
+
+    cold, warm = run("0"), run("1")
+    for (zc, (itc, errc)), (zw, (itw, errw)) in zip(cold, warm):
+        assert itc == itw, (itc, itw)
+        for a, b, ec, ew in zip(zc, zw, errc, errw):
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
+            if max(ec, ew) > 1e-3:           # (a full-rank layer's error is sqrt of fp32 rounding noise: ~1e-4 either way)
+                assert abs(ec - ew) <= 1e-6
+
+
 def test_admm_update_every_distinct_resnet50_shape_vs_oracle(dev):
     """Headline table: Z, U and the logged residual of EVERY distinct layer shape (12) against the oracle."""
     from tadmm import workloads
