@@ -88,6 +88,11 @@ void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, cons
 // verdict_pinned: [1 + nprob] ints of device-visible pinned host memory)
 void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,
                         int* verdict_pinned, hipStream_t s);
+// Largest eigen-problem the Jacobi kernels take: rows longer than the LDS-resident pair (~1270) go through the streamed
+// pair kernel (jacobi_tick_stream_kernel); the bound itself is the 64 KiB eigenvalue table of eig_sort_kernel.
+constexpr int kJacobiMaxN = 8160;
+bool jacobi_size_supported(int n);
+size_t jacobi_tick_stream_lds_bytes();
 size_t jacobi_tick_lds_bytes(int ld_max);    // dynamic LDS of a tick1 launch whose largest problem has row length ld_max
 size_t jacobi_tick2_lds_bytes(int ld_max);   // same for the LDS-resident super-pair kernel
 bool jacobi_tick2_fits(int ld_max);

@@ -429,6 +429,127 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// tick1, streamed: the pair kernel for problems whose 16 columns do not fit the LDS (ld > ~1270: the
+// 4096-wide classifier layers of the VGG tables).  Same tournament, same inner solve, same descriptors
+// and block map as jacobi_tick_kernel (self_mode = 0); the columns pass through the LDS in chunks of
+// kStreamChunk rows twice -- once for H = Xp^T Xp (the four waves keep their partial tiles in
+// registers across chunks), once for Xp <- Xp Q (second read mostly from L2 / Infinity Cache).
+// Dynamic LDS (doubles): X[16][kStreamChunk + 2] | PairScratch
+// ------------------------------------------------------------------------------------------------
+constexpr int kStreamChunk = 1024;
+
+__device__ __forceinline__ void stream_load_chunk(double* __restrict__ Xs, const double* __restrict__ XT, int ld,
+                                                  int ba, int bb, int c0, int len, int tid) {
+  constexpr int ldp = kStreamChunk + 2;
+  const int c2n = len >> 1;                        // double2 per row of the chunk (len % 32 == 0)
+  const int total = kPair * c2n;
+  constexpr int kBatch = 8;
+  for (int base = tid; base < total; base += 256 * kBatch) {
+    double2_t v[kBatch];
+    int dst[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int idx = base + k * 256;
+      const bool ok = idx < total;
+      const int row = ok ? idx / c2n : 0, c2 = ok ? idx - row * c2n : 0;
+      const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
+      dst[k] = ok ? row * ldp + 2 * c2 : -1;
+      v[k] = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + c0 + 2 * c2);
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k)
+      if (dst[k] >= 0) *reinterpret_cast<double2_t*>(Xs + dst[k]) = v[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void jacobi_tick_stream_kernel(const EigDesc* __restrict__ descs,
+                                                                 const BlockRef* __restrict__ map, int tick,
+                                                                 double tol) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const BlockRef br = map[blockIdx.x];
+  const EigDesc d = descs[br.prob];
+  if (*d.done) return;
+  const int nb = d.nb;
+  const int steps = nb - 1;
+  const int sweep = tick / steps;
+  const int step = tick - sweep * steps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (step == 0 && sweep > 0) {
+    if (d.off[(sweep - 1) & 1] < tol) {
+      if (br.local == 0 && tid == 0) *d.done = 1;
+      return;
+    }
+  }
+  constexpr int ldp = kStreamChunk + 2;
+  const int ld = d.ld;
+  double* Xs = smem;
+  const PairScratch S = carve_scratch(Xs + kPair * ldp);
+  int ba, bb;
+  rr_pair(nb, step, br.local, ba, bb);
+  const int r = lane & 15, q = lane >> 4;
+  double* __restrict__ XT = d.XT;
+
+  // ---- 1. H = Xp^T Xp over all chunks ----
+  double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  for (int c0 = 0; c0 < ld; c0 += kStreamChunk) {
+    const int len = min(kStreamChunk, ld - c0);    // multiple of 32
+    if (c0) __syncthreads();                       // the previous chunk has been consumed
+    stream_load_chunk(Xs, XT, ld, ba, bb, c0, len, tid);
+    __syncthreads();
+    const int per = len >> 2;                      // rows of the chunk per wave (multiple of 8)
+    const double* row = Xs + r * ldp;
+    for (int i = wave * per; i < (wave + 1) * per; i += 8) {
+      const double2_t v = *reinterpret_cast<const double2_t*>(row + i + 2 * q);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, v.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, v.y, acc1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) S.red[wave * 256 + lane * 4 + e] = acc0[e] + acc1[e];
+  if (step == steps - 1 && br.local == 0 && tid == 0) d.off[(sweep + 1) & 1] = 0.0;
+  __syncthreads();
+  pair_gram_reduce(S, tid);
+  __syncthreads();
+  if (wave == 0) {
+    const double mx = pair_inner_solve_fast(S, lane, d.off[2], tol, step == 0, nullptr);
+    if (lane == 0)
+      atomicMax(reinterpret_cast<unsigned long long*>(&d.off[sweep & 1]), (unsigned long long)__double_as_longlong(mx));
+  }
+  __syncthreads();
+  if (!*S.rotated) return;
+
+  // ---- 2. Xp <- Xp * Q chunk by chunk ----
+  double qa[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) qa[t] = S.Q[4 * t + q][r];
+  int64_t orow[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int a = q + 4 * e;
+    orow[e] = (int64_t)((a < kJB) ? (ba * kJB + a) : (bb * kJB + (a - kJB))) * ld;
+  }
+  const int last0 = ((ld - 1) / kStreamChunk) * kStreamChunk;     // the chunk still in the LDS
+  for (int c0 = last0; c0 >= 0; c0 -= kStreamChunk) {             // backwards: the resident chunk first
+    const int len = min(kStreamChunk, ld - c0);
+    if (c0 != last0) {
+      __syncthreads();
+      stream_load_chunk(Xs, XT, ld, ba, bb, c0, len, tid);
+      __syncthreads();
+    }
+    const int ntile = len >> 4;
+    for (int it = wave; it < ntile; it += 4) {
+      const int col = it * 16 + r;
+      double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[t], Xs[(4 * t + q) * ldp + col], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) XT[orow[e] + c0 + col] = acc[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tick2: one workgroup (512 threads) = one super-pair of 2 x 16 columns, LDS resident.
 // Dynamic LDS (doubles): X[32][ldp] | PairScratch[2]
 // Sub-blocks of 8 rows in the slab: 0,1 = super-block A ; 2,3 = super-block B.
@@ -1214,6 +1335,8 @@ void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, cons
   hipLaunchKernelGGL(jacobi_init_kernel, dim3(nprob), dim3(256), 0, s, descs_dev, skip, prev_dev);
 }
 
+size_t jacobi_tick_stream_lds_bytes() { return ((size_t)kPair * (kStreamChunk + 2) + kPairScratchDoubles) * 8; }
+bool jacobi_size_supported(int n) { return n >= 1 && n <= kJacobiMaxN; }
 size_t jacobi_tick_lds_bytes(int ld_max) { return ((size_t)kPair * (ld_max + 2) + kPairScratchDoubles) * 8; }
 size_t jacobi_tick3_lds_bytes(int ld_max) {
   return ((size_t)kSuper * (ld_max + 2) + 2048 + 2 * (3 * kPair * kHP)) * 8 + 16;
@@ -1240,7 +1363,7 @@ void launch_jacobi_tick3(const EigDesc* descs_dev, const BlockRef* map_dev, int 
             jacobi_tick3_lds_bytes(ld_max));
 }
 size_t jacobi_tick2_lds_bytes(int ld_max) { return ((size_t)kSuper * (ld_max + 2) + 2 * kPairScratchDoubles) * 8; }
-bool jacobi_tick2_fits(int ld_max) { return jacobi_tick2_lds_bytes(ld_max) <= 160 * 1024; }
+bool jacobi_tick2_fits(int ld_max) { return jacobi_tick2_lds_bytes(ld_max) <= 160 * 1024 - 256; }
 
 void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, int ld_max, hipStream_t s) {
@@ -1269,8 +1392,11 @@ void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int n
   if (!attr_set) {   // allow the full 160 KiB of a CU as dynamic LDS (default cap is 64 KiB)
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // tick2 carries 256 bytes of static LDS: asking for the full 160 KiB as dynamic LDS is refused (invalid argument)
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick2_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_tick_stream_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e1 != hipSuccess || e2 != hipSuccess)
       fprintf(stderr, "[tadmm] hipFuncSetAttribute(max dynamic LDS): %s / %s\n", hipGetErrorString(e1),
               hipGetErrorString(e2));
@@ -1280,6 +1406,9 @@ void launch_jacobi_tick(const EigDesc* descs_dev, const BlockRef* map_dev, int n
   if (super)
     hipLaunchKernelGGL(jacobi_tick2_kernel, dim3(nblocks), dim3(512), lds_bytes, s, descs_dev, map_dev, tick, tol,
                        inner_sweeps);
+  else if (lds_bytes > 160 * 1024)      // rows too long for an LDS-resident pair: streamed pair kernel
+    hipLaunchKernelGGL(jacobi_tick_stream_kernel, dim3(nblocks), dim3(256), jacobi_tick_stream_lds_bytes(), s, descs_dev,
+                       map_dev, tick, tol);
   else
     hipLaunchKernelGGL(jacobi_tick_kernel, dim3(nblocks), dim3(256), lds_bytes, s, descs_dev, map_dev, tick, tol,
                        inner_sweeps, 0);
@@ -1295,7 +1424,7 @@ void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nbl
 }
 void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip) {
   if (nprob <= 0) return;
-  hipLaunchKernelGGL(eig_sort_kernel, dim3(nprob), dim3(256), 16384, s, descs_dev, skip);
+  hipLaunchKernelGGL(eig_sort_kernel, dim3(nprob), dim3(256), (size_t)kJacobiMaxN * 8, s, descs_dev, skip);
 }
 void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                         const int32_t* skip) {

@@ -110,9 +110,9 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     // row length of the eigen-solver's X image: whole 1 KiB chunks (tick3 wants ld % 64 == 0)
     st.ld = (int)align_up(st.N, st.N <= kLd128Max ? 128 : 32);
     st.nt = (st.N + 31) / 32;
-    if (!st.skip && jacobi_tick_lds_bytes(st.ld) > 160 * 1024)
-      CTX_FAIL(h, TADMM_ERR_UNSUPPORTED,
-               "TT step %d: eigen-problem of size %d exceeds the LDS-resident Jacobi kernels (max ~1270)", s, st.N);
+    if (!st.skip && !jacobi_size_supported(st.N))
+      CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "TT step %d: eigen-problem of size %d exceeds the Jacobi kernels (max %d)", s,
+               st.N, kJacobiMaxN);
     const int64_t K = st.trans ? st.m : st.cols;
     const int ntp = st.nt * (st.nt + 1) / 2;
     // split-K only where a problem has too few tiles to matter beside the others of its level (levels batch

@@ -196,8 +196,8 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     for (int k = 0; k < 4; ++k) {
       const OpGeom& g = og[k * n + l];
       t.reff[k] = g.r_eff;
-      if (jacobi_tick_lds_bytes(g.ld) > 160 * 1024)
-        CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "Tucker layer %d: eigen-problem of size %d exceeds the LDS-resident Jacobi kernels", l, g.N);
+      if (!jacobi_size_supported(g.N))
+        CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "Tucker layer %d: eigen-problem of size %d exceeds the Jacobi kernels (max %d)", l, g.N, kJacobiMaxN);
       xtb = std::max(xtb, (size_t)g.Npad * g.ld * 8);
       gpb = std::max(gpb, (size_t)g.ksplit * (g.nt * (g.nt + 1) / 2) * 1024 * 8);
       vsb = std::max(vsb, (size_t)g.N * std::max(1, g.r_eff) * 4);

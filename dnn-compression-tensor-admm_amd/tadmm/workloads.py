@@ -56,6 +56,25 @@ def deit_small_shape(name: str) -> Tuple[int, ...]:
     raise KeyError(name)
 
 
+# VGG-16 convolutions 2..13 in order (the first one, 3 -> 64, is in no table); the timm-style head the tables are keyed
+# by (`pre_logits.fc1` = 7x7 convolution 512 -> 4096, `pre_logits.fc2` = 1x1 convolution 4096 -> 4096)
+_VGG16_CONVS = [(64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (256, 256), (512, 256), (512, 512), (512, 512),
+                (512, 512), (512, 512), (512, 512)]
+
+
+def _vgg16_shape_fn(table_key: str):
+    feats = [n for n in hp.table(table_key).ranks if n.startswith("features.")]
+
+    def fn(name: str) -> Tuple[int, ...]:
+        if name == "pre_logits.fc1.weight":
+            return (4096, 512, 7, 7)
+        if name == "pre_logits.fc2.weight":
+            return (4096, 4096, 1, 1)
+        o, i = _VGG16_CONVS[feats.index(name)]
+        return (o, i, 3, 3)
+    return fn
+
+
 CONFIGS = {
     # name: (hp table key, format, shape function)
     "resnet50_tt": ("tt_resnet50_hp.HyperParamsDictGeneralRatio3x", "tt", resnet50_shape),
@@ -63,6 +82,10 @@ CONFIGS = {
     "deit_small_tt": ("tt_deit_small_patch16_224_hp.HyperParamsDictRatio2x", "tt", deit_small_shape),
     "resnet32_tk": ("tk_resnet32_hp.HyperParamsDictRatio3x", "tk", resnet_cifar_shape),
     "resnet32_tt": ("tt_resnet32_hp.HyperParamsDictRatio3x", "tt", resnet_cifar_shape),
+    # 4096-wide classifier Grams: streamed Jacobi pairs (csrc/jacobi.hip: jacobi_tick_stream_kernel)
+    "vgg16_tk": ("tk_vgg16_hp.HyperParamsDictRatio2x", "tk", _vgg16_shape_fn("tk_vgg16_hp.HyperParamsDictRatio2x")),
+    "vgg16_bn_tk": ("tk_vgg16_bn_hp.HyperParamsDictRatio10x", "tk",
+                    _vgg16_shape_fn("tk_vgg16_bn_hp.HyperParamsDictRatio10x")),
 }
 
 

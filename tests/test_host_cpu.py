@@ -213,10 +213,9 @@ def test_layer_constructors_shapes_and_keys():
 
 
 def test_eigen_problem_size_limit_is_reported_not_hidden():
-    """The LDS-resident Jacobi kernels hold 16 fp64 columns of the Gram matrix per workgroup: N <= ~1270.  Bigger
-    eigen-problems (the 4096-wide `pre_logits.fc1/fc2` entries of the tk_vgg16 / tk_vgg16_bn tables, any SVD layer
-    with min(out, in) above the limit) must be refused at plan time with TADMM_ERR_UNSUPPORTED and a message -- no
-    silent wrong answer, no crash (documented in DESIGN.md and README.md)."""
+    """Eigen-problems up to N = 8160 are taken: rows that do not fit the LDS-resident pair kernels (N > ~1270: the
+    4096-wide `pre_logits.fc1/fc2` entries of the tk_vgg16 / tk_vgg16_bn tables) go through the streamed pair kernel.
+    Beyond that the plan is refused with TADMM_ERR_UNSUPPORTED and a message -- no silent wrong answer, no crash."""
     import ctypes as C
     from tadmm import _cabi
     lib = _cabi.load()
@@ -227,11 +226,15 @@ def test_eigen_problem_size_limit_is_reported_not_hidden():
     ok = (_cabi.LayerDesc * 1)(_cabi.make_layer_desc(_cabi.KIND_SVD, [1024, 1024], None, 64))
     assert lib.tadmm_plan_workspace_bytes(h, 1, ok, C.byref(size)) == 0 and size.value > 0
     big = (_cabi.LayerDesc * 1)(_cabi.make_layer_desc(_cabi.KIND_SVD, [4096, 4096], None, 512))
-    rc = lib.tadmm_plan_workspace_bytes(h, 1, big, C.byref(size))
+    assert lib.tadmm_plan_workspace_bytes(h, 1, big, C.byref(size)) == 0 and size.value > 4096 * 4096 * 8
+    tk = (_cabi.LayerDesc * 1)(_cabi.make_layer_desc(_cabi.KIND_TUCKER2, [4096, 512, 7, 7], None, [512, 256]))
+    assert lib.tadmm_tucker_workspace_bytes(h, 1, tk, C.byref(size)) == 0 and size.value > 0
+    huge = (_cabi.LayerDesc * 1)(_cabi.make_layer_desc(_cabi.KIND_SVD, [16384, 9000], None, 512))
+    rc = lib.tadmm_plan_workspace_bytes(h, 1, huge, C.byref(size))
     assert rc < 0
     msg = lib.tadmm_last_error(h).decode()
-    assert "4096" in msg and "exceeds" in msg
-    tk = (_cabi.LayerDesc * 1)(_cabi.make_layer_desc(_cabi.KIND_TUCKER2, [4096, 512, 7, 7], None, [512, 256]))
+    assert "9000" in msg and "exceeds" in msg
+    tk = (_cabi.LayerDesc * 1)(_cabi.make_layer_desc(_cabi.KIND_TUCKER2, [16384, 9000, 3, 3], None, [512, 256]))
     assert lib.tadmm_tucker_workspace_bytes(h, 1, tk, C.byref(size)) < 0
     assert "exceeds" in lib.tadmm_last_error(h).decode()
     lib.tadmm_destroy(h)
