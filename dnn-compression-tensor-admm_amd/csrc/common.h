@@ -107,8 +107,10 @@ bool jacobi_tick3_fits(int ld_max);
 // round-1 update).  Needs launch_jacobi_self on the first tick of every sweep (it refreshes EigDesc::sblk).
 void launch_jacobi_tick3(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                          int ld_max, hipStream_t s);
-// row lengths up to this are padded to whole 1 KiB chunks (128 doubles), longer ones to 32 doubles
-constexpr int kLd128Max = 1152;
+// rows of an eigen-solver image are whole 1 KiB chunks (128 doubles: LDS-DMA loads).  The LDS-resident pair kernel
+// holds 16 such rows up to ld = 1152; longer rows go through the streamed pair kernel.
+constexpr int kLdResidentMax = 1152;
+static inline int eig_ld(int N) { return (N + 127) / 128 * 128; }
 // once-per-sweep companion of tick3 (tick1 in self mode): within-block pairs + refresh of the carried self-Grams
 void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, int tick, double tol,
                         int inner_sweeps, int ld_max, hipStream_t s);

@@ -438,28 +438,22 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
 // ------------------------------------------------------------------------------------------------
 constexpr int kStreamChunk = 1024;
 
+// LDS-DMA, 1 KiB pieces, every piece of a wave in flight at once (128 KiB per workgroup): the pass is bound by
+// what one CU pulls from L2 / Infinity Cache, not by a handful of register loads per thread
 __device__ __forceinline__ void stream_load_chunk(double* __restrict__ Xs, const double* __restrict__ XT, int ld,
-                                                  int ba, int bb, int c0, int len, int tid) {
+                                                  int ba, int bb, int c0, int len, int wave, int lane) {
   constexpr int ldp = kStreamChunk + 2;
-  const int c2n = len >> 1;                        // double2 per row of the chunk (len % 32 == 0)
-  const int total = kPair * c2n;
-  constexpr int kBatch = 8;
-  for (int base = tid; base < total; base += 256 * kBatch) {
-    double2_t v[kBatch];
-    int dst[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int idx = base + k * 256;
-      const bool ok = idx < total;
-      const int row = ok ? idx / c2n : 0, c2 = ok ? idx - row * c2n : 0;
-      const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
-      dst[k] = ok ? row * ldp + 2 * c2 : -1;
-      v[k] = *reinterpret_cast<const double2_t*>(XT + (int64_t)grow * ld + c0 + 2 * c2);
-    }
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k)
-      if (dst[k] >= 0) *reinterpret_cast<double2_t*>(Xs + dst[k]) = v[k];
+  const int cpr = len >> 7;                        // 1 KiB pieces per row of the chunk (len % 128 == 0)
+  const int npiece = kPair * cpr;
+  for (int c = wave; c < npiece; c += 4) {
+    const int row = c / cpr, ch = c - row * cpr;
+    const int grow = (row < kJB) ? (ba * kJB + row) : (bb * kJB + (row - kJB));
+    const double* src = XT + (int64_t)grow * ld + c0 + ch * 128 + lane * 2;
+    double* dst = Xs + row * ldp + ch * 128;       // wave-uniform
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
+  __builtin_amdgcn_s_waitcnt(0);
 }
 
 __global__ __launch_bounds__(256) void jacobi_tick_stream_kernel(const EigDesc* __restrict__ descs,
@@ -492,9 +486,9 @@ __global__ __launch_bounds__(256) void jacobi_tick_stream_kernel(const EigDesc* 
   // ---- 1. H = Xp^T Xp over all chunks ----
   double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
   for (int c0 = 0; c0 < ld; c0 += kStreamChunk) {
-    const int len = min(kStreamChunk, ld - c0);    // multiple of 32
+    const int len = min(kStreamChunk, ld - c0);    // multiple of 128 (eig_ld)
     if (c0) __syncthreads();                       // the previous chunk has been consumed
-    stream_load_chunk(Xs, XT, ld, ba, bb, c0, len, tid);
+    stream_load_chunk(Xs, XT, ld, ba, bb, c0, len, wave, lane);
     __syncthreads();
     const int per = len >> 2;                      // rows of the chunk per wave (multiple of 8)
     const double* row = Xs + r * ldp;
@@ -533,7 +527,7 @@ __global__ __launch_bounds__(256) void jacobi_tick_stream_kernel(const EigDesc* 
     const int len = min(kStreamChunk, ld - c0);
     if (c0 != last0) {
       __syncthreads();
-      stream_load_chunk(Xs, XT, ld, ba, bb, c0, len, tid);
+      stream_load_chunk(Xs, XT, ld, ba, bb, c0, len, wave, lane);
       __syncthreads();
     }
     const int ntile = len >> 4;

@@ -108,7 +108,7 @@ static int build_geom(tadmm_handle h, const tadmm_layer_desc& din, LayerGeom& g)
     st.Npad = (int)align_up(st.N, 4 * kJB);     // whole super-pairs of 2 x 16 columns
     st.nb = st.Npad / kJB;
     // row length of the eigen-solver's X image: whole 1 KiB chunks (tick3 wants ld % 64 == 0)
-    st.ld = (int)align_up(st.N, st.N <= kLd128Max ? 128 : 32);
+    st.ld = eig_ld(st.N);
     st.nt = (st.N + 31) / 32;
     if (!st.skip && !jacobi_size_supported(st.N))
       CTX_FAIL(h, TADMM_ERR_UNSUPPORTED, "TT step %d: eigen-problem of size %d exceeds the Jacobi kernels (max %d)", s,
@@ -1406,7 +1406,7 @@ static void gram_geom(int m, int n, StepGeom& st) {
   st.N = std::min(m, n);
   st.Npad = (int)align_up(st.N, 4 * kJB);
   st.nb = st.Npad / kJB;
-  st.ld = (int)align_up(st.N, st.N <= kLd128Max ? 128 : 32);
+  st.ld = eig_ld(st.N);
   st.nt = (st.N + 31) / 32;
   const int64_t K = st.trans ? m : n;
   const int ntp = st.nt * (st.nt + 1) / 2;
@@ -1470,7 +1470,7 @@ int tadmm_gram_f64(tadmm_handle h, const float* A, int m, int n, double* G, int 
 }
 
 size_t tadmm_eigh_scratch_bytes(int N) {
-  const size_t Npad = align_up(N, 4 * kJB), ld = align_up(N, N <= kLd128Max ? 128 : 32);
+  const size_t Npad = align_up(N, 4 * kJB), ld = (size_t)eig_ld(N);
   return align_up(Npad * ld * 8, 256) + align_up(sizeof(EigDesc), 256) + 4 * align_up(Npad * sizeof(BlockRef), 256) +
          align_up(Npad * 8, 256) * 2 + align_up(Npad * 4, 256) + 1024 + align_up((Npad / 16) * 256 * 8, 256);
 }
@@ -1481,7 +1481,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   if (!h || !G || !evals_out || !evecs_out || !scratch || N <= 0) return TADMM_ERR_INVALID;
   if (scratch_bytes < tadmm_eigh_scratch_bytes(N)) CTX_FAIL(h, TADMM_ERR_WORKSPACE, "eigh scratch too small");
   hipStream_t s = (hipStream_t)stream_;
-  const int Npad = (int)align_up(N, 4 * kJB), ld = (int)align_up(N, N <= kLd128Max ? 128 : 32),
+  const int Npad = (int)align_up(N, 4 * kJB), ld = eig_ld(N),
             nb = Npad / kJB;
   int mode = getenv("TADMM_JACOBI_MODE") ? atoi(getenv("TADMM_JACOBI_MODE")) : 3;
   if (mode == 3 && (!jacobi_tick3_fits(ld) || ld % 64)) mode = 1;

@@ -46,7 +46,7 @@ OpGeom op_geom(int m, int n, int r) {
   g.N = std::min(m, n);
   g.Npad = (int)align_up(g.N, 4 * kJB);
   g.nb = g.Npad / kJB;
-  g.ld = (int)align_up(g.N, g.N <= kLd128Max ? 128 : 32);
+  g.ld = eig_ld(g.N);
   g.nt = (g.N + 31) / 32;
   const int64_t K = g.trans ? m : n;
   const int ntp = g.nt * (g.nt + 1) / 2;

@@ -119,7 +119,7 @@ def test_vgg16_bn_table_through_admm(dev):
     """The whole tk_vgg16_bn_hp.HyperParamsDictRatio10x table through ADMM.update (admm.py:42-78): twelve 3x3 Tucker
     convs, `pre_logits.fc1` (4096 x 512 x 7 x 7, ranks [288, 288]: mode-0 Gram 4096 wide) and `pre_logits.fc2`
     (4096 x 4096 x 1 x 1, entry [512]: the SVD branch admm.py:129-139 inside a "tk" table).  Plan creation used to
-    refuse this table.  Four convs and fc2 against the oracle; fc1 by invariants (its host HOSVD takes minutes)."""
+    refuse this table.  Two convs and fc2 against the oracle; fc1 by invariants (its host HOSVD takes minutes)."""
     from tadmm import workloads
     from tadmm.admm import ADMM
     model, hp, fmt = workloads.build("vgg16_bn_tk", seed=0)
@@ -130,8 +130,8 @@ def test_vgg16_bn_table_through_admm(dev):
     a = ADMM(model, 1e-3, hp, fmt, dev, log=True)
     a.update(update_u=False)
     a.update()
-    # oracle on one conv per stage and on fc2 (the host HOOI of all twelve convs takes two minutes)
-    checked = {"features.3.weight", "features.14.weight", "features.27.weight", "features.40.weight",
+    # oracle on two convs and on fc2 (the host HOOI of all twelve convs takes two minutes)
+    checked = {"features.3.weight", "features.27.weight",
                "pre_logits.fc2.weight"}
     for k in names:
         got = a.z[k].cpu().numpy()
