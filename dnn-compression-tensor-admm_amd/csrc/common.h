@@ -88,7 +88,7 @@ void launch_jacobi_init(const EigDesc* descs_dev, int nprob, hipStream_t s, cons
 // verdict_pinned: [1 + nprob] ints of device-visible pinned host memory)
 void launch_jacobi_conv(const EigDesc* descs_dev, int nprob, int tick, double tol, bool super, double* prev_dev,
                         int* verdict_pinned, hipStream_t s);
-// Largest eigen-problem the Jacobi kernels take: rows longer than the LDS-resident pair (~1270) go through the streamed
+// Largest eigen-problem the Jacobi kernels take: rows longer than the LDS-resident pair (N = 1152) go through the streamed
 // pair kernel (jacobi_tick_stream_kernel); the bound itself is the 64 KiB eigenvalue table of eig_sort_kernel.
 constexpr int kJacobiMaxN = 8160;
 bool jacobi_size_supported(int n);

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void jacobi_tick_kernel(const EigDesc* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// tick1, streamed: the pair kernel for problems whose 16 columns do not fit the LDS (ld > ~1270: the
+// tick1, streamed: the pair kernel for problems whose 16 columns do not fit the LDS (ld > 1152: the
 // 4096-wide classifier layers of the VGG tables).  Same tournament, same inner solve, same descriptors
 // and block map as jacobi_tick_kernel (self_mode = 0); the columns pass through the LDS in chunks of
 // kStreamChunk rows twice -- once for H = Xp^T Xp (the four waves keep their partial tiles in

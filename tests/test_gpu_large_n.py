@@ -1,4 +1,4 @@
-"""Eigen-problems that do not fit the LDS-resident Jacobi kernels (N > ~1270; the 4096-wide classifier layers of the
+"""Eigen-problems that do not fit the LDS-resident Jacobi kernels (N > 1152; the 4096-wide classifier layers of the
 tk_vgg16 / tk_vgg16_bn tables, admm.py:121-127 / :141-149 on `pre_logits.fc1/fc2`): the streamed pair kernel
 (`jacobi_tick_stream_kernel`) against numpy / the oracle, standalone and inside the TT / SVD and Tucker plans.
 

@@ -213,7 +213,7 @@ def test_layer_constructors_shapes_and_keys():
 
 
 def test_eigen_problem_size_limit_is_reported_not_hidden():
-    """Eigen-problems up to N = 8160 are taken: rows that do not fit the LDS-resident pair kernels (N > ~1270: the
+    """Eigen-problems up to N = 8160 are taken: rows that do not fit the LDS-resident pair kernels (N > 1152: the
     4096-wide `pre_logits.fc1/fc2` entries of the tk_vgg16 / tk_vgg16_bn tables) go through the streamed pair kernel.
     Beyond that the plan is refused with TADMM_ERR_UNSUPPORTED and a message -- no silent wrong answer, no crash."""
     import ctypes as C
