@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -235,6 +236,8 @@ struct EigGroup {
   bool aligned = false;             // every EigDesc carries period = gsteps: all sweeps start at the same tick
   bool warm = false;                // some EigDesc of the group carries a warm-start image (jacobi_small: second LDS image)
   const int* row_len = nullptr;     // per problem: ld of its X image (timing only: executed flops of a tick)
+  std::function<void(hipStream_t)> after_init;   // tick path only: queued right after jacobi_init (which takes the scale
+                                                 // of a problem from X = G), e.g. the warm start X <- V G of big problems
   // debug only
   const double* off_dev = nullptr; const int* done_dev = nullptr;
 };
@@ -264,6 +267,7 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
     }
   }
   launch_jacobi_init(g.ed, g.neig, s, g.skip, g.prev_dev);
+  if (g.after_init) g.after_init(s);
   if (g.gsteps == 0) return TADMM_OK;      // every problem is a single block: nothing to rotate
   bool all_done = false;
   int tick = 0, gs = 0, pending = -1, needed = 0;

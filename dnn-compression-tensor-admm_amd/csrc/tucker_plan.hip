@@ -65,7 +65,17 @@ struct Group {   // descriptors + block map of one grouped launch (offsets into 
   int nblocks = 0;
 };
 
+// Warm start of a streamed (N > 1152) HOOI eigen-solve: X0 = V G with V the eigenvectors of the same mode's previous solve.
+// The solve's scale is taken from X = G first (jacobi_init), then G is copied aside and one gated fp64 tile GEMM
+// rewrites the image; after the solve the normalised columns of X become the next V (bigwarm_* kernels).
+struct BigWarm {
+  int layer = 0, Npad = 0, ld = 0, nblocks = 0;
+  size_t V = 0, Gt = 0, XT = 0, ok = 0;      // workspace offsets: [Npad][ld] eigenvectors, G copy, the X image, int flag
+  size_t desc_off = 0, map_off = 0;           // one DgemmDesc + its 64 x 64 tile map
+};
+
 struct Lsv {     // one grouped "leading singular vectors" phase over all layers
+  std::vector<BigWarm> big;
   Group gram_p, gram_r, tick, self, norm, ext, xg;
   size_t eig_desc_off = 0;
   std::vector<int> players;
@@ -79,6 +89,7 @@ struct TLayer {
   int64_t numel = 0;
   size_t T = 0, P = 0, C = 0, Uo = 0, Ui = 0, Vs = 0, XT = 0, lam = 0, order = 0, sigma = 0, sblk = 0, gpart = 0;
   size_t warm[2] = {0, 0};        // eigenvectors of the previous HOOI solve of modes 0 / 1 (problems of <= 64 columns)
+  size_t bigV[2] = {0, 0}, bigG = 0;   // the same for streamed problems (N > kLdResidentMax): [Npad][ld] + a G copy
   int reff[4] = {0, 0, 0, 0};   // vectors each of the four singular-vector requests can deliver
 };
 
@@ -91,7 +102,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* const* __restri
   const float* __restrict__ x = ptrs[l];
   const int64_t n = numel[l];
   double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) { const double v = x[i]; acc += v * v; }
+  if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    // 16-byte loads, four in flight per thread (one workgroup reads the whole tensor: latency, not bandwidth, is the limit)
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    const int64_t n4 = n >> 2;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+      const float4 u0 = x4[i], u1 = x4[i + 256], u2 = x4[i + 512], u3 = x4[i + 768];
+      a0 += (double)u0.x * u0.x + (double)u0.y * u0.y + (double)u0.z * u0.z + (double)u0.w * u0.w;
+      a1 += (double)u1.x * u1.x + (double)u1.y * u1.y + (double)u1.z * u1.z + (double)u1.w * u1.w;
+      a2 += (double)u2.x * u2.x + (double)u2.y * u2.y + (double)u2.z * u2.z + (double)u2.w * u2.w;
+      a3 += (double)u3.x * u3.x + (double)u3.y * u3.y + (double)u3.z * u3.z + (double)u3.w * u3.w;
+    }
+    for (; i < n4; i += 256) {
+      const float4 u0 = x4[i];
+      a0 += (double)u0.x * u0.x + (double)u0.y * u0.y + (double)u0.z * u0.z + (double)u0.w * u0.w;
+    }
+    acc = (a0 + a1) + (a2 + a3);
+    for (int64_t j = (n4 << 2) + threadIdx.x; j < n; j += 256) { const double v = x[j]; acc += v * v; }
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += 256) { const double v = x[i]; acc += v * v; }
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -99,6 +131,36 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* const* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) out[l] = red[0];
+}
+
+// verdict on a finished streamed solve: may its columns serve as the next start?  (converged, every genuine column
+// normalisable: norm above 1e-8 of the largest -- below that the direction is rounding residue)
+__global__ __launch_bounds__(256) void bigwarm_check_kernel(const EigDesc* __restrict__ descs, int prob,
+                                                            const int32_t* __restrict__ skip, int32_t* __restrict__ ok) {
+  if (skip && skip[prob]) return;
+  const EigDesc d = descs[prob];
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = *d.done ? 0 : 1;
+  __syncthreads();
+  const double floor_ = 1e-8 * d.lam[d.order[0]];
+  int b = 0;
+  for (int j = threadIdx.x; j < d.N; j += 256) b |= !(d.lam[j] > floor_ && d.lam[j] > 0.0);
+  if (b) bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) *ok = bad ? 0 : 1;
+}
+// V[j][:] = X[j][:] / |X[j]| (one wave per row; rows beyond N and the padding stay zero)
+__global__ __launch_bounds__(256) void bigwarm_save_kernel(const EigDesc* __restrict__ descs, int prob,
+                                                           const int32_t* __restrict__ skip,
+                                                           const int32_t* __restrict__ ok, double* __restrict__ V) {
+  if ((skip && skip[prob]) || !*ok) return;
+  const EigDesc d = descs[prob];
+  const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= d.Npad) return;
+  const double inv = j < d.N ? 1.0 / d.lam[j] : 0.0;
+  const double* __restrict__ x = d.XT + (int64_t)j * d.ld;
+  double* __restrict__ v = V + (int64_t)j * d.ld;
+  for (int i = lane; i < d.ld; i += 64) v[i] = x[i] * inv;
 }
 
 // tensorly's stopping rule after HOOI sweep `it` (0-based), per layer; err: [2][n] ping-pong of the relative errors
@@ -213,9 +275,16 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     t.sigma = ar.take(npad * 8);
     t.order = ar.take(npad * 4);
     t.sblk = ar.take((npad / 16) * 256 * 8);
+    t.bigG = 0;          // (the layout runs twice on the same TLayer: sizes, then addresses)
     for (int k = 0; k < 2; ++k) {
+      t.bigV[k] = 0;
       const int np = og[(2 + k) * n + l].Npad;
       t.warm[k] = jacobi_small_fits(np) ? ar.take((size_t)np * np * 8) : 0;
+      const OpGeom& gk = og[(2 + k) * n + l];
+      if (gk.ld > kLdResidentMax && warm_start_on()) {
+        t.bigV[k] = ar.take((size_t)gk.Npad * gk.ld * 8);
+        if (!t.bigG) t.bigG = ar.take(xtb);
+      }
     }
   }
   P->off_off = ar.take((size_t)n * 3 * 8);
@@ -293,6 +362,7 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     v.ld_max = 0;
     v.npad_max = 0;
     v.warm = false;
+    v.big.clear();
     for (int l = 0; l < n; ++l) {
       v.ld_max = std::max(v.ld_max, og[k * n + l].ld);
       v.npad_max = std::max(v.npad_max, og[k * n + l].Npad);
@@ -330,6 +400,28 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
         e.warm = (double*)dev(t.warm[k - 2]);
         e.warm_ok = (int32_t*)dev(P->warm_ok_off) + 2 * l + (k - 2);
         v.warm = true;
+      }
+      if (k >= 2 && t.bigV[k - 2]) {
+        BigWarm bw;
+        bw.layer = l; bw.Npad = g.Npad; bw.ld = g.ld;
+        bw.V = t.bigV[k - 2]; bw.Gt = t.bigG; bw.XT = t.XT;
+        bw.ok = P->warm_ok_off + (size_t)(2 * l + (k - 2)) * 4;
+        DgemmDesc dg;
+        memset(&dg, 0, sizeof dg);
+        dg.A = (const double*)dev(bw.V); dg.B = (const double*)dev(bw.Gt); dg.C = (const double*)dev(bw.XT);
+        dg.selA = dg.selB = dg.selC = dg.selP = dg.selQ = -1;
+        dg.M = dg.N = dg.K = g.Npad; dg.lda = dg.ldb = dg.ldc = g.ld;
+        dg.tiles_m = g.Npad / 32; dg.tiles_n = g.Npad / 32;
+        dg.gate = (const int32_t*)dev(bw.ok); dg.gate_min = 1;      // no-op while the previous solve left no usable V
+        std::vector<BlockRef> m64;
+        const int t64 = (g.Npad + 63) / 64;
+        for (int b = 0; b < t64 * t64; ++b) m64.push_back(BlockRef{0, b});
+        bw.nblocks = (int)m64.size();
+        bw.desc_off = da.take(sizeof(DgemmDesc));
+        bw.map_off = da.take(m64.size() * sizeof(BlockRef));
+        put(bw.desc_off, &dg, sizeof dg);
+        put(bw.map_off, m64.data(), m64.size() * sizeof(BlockRef));
+        v.big.push_back(bw);
       }
       if (direct) { e.mode = 0; e.out_a = factor; e.ldo = r_full; }
       else { e.mode = 3; e.out_a = (float*)dev(t.Vs); e.ldo = 0; }
@@ -510,6 +602,18 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     eg.skip = sk;
     eg.npad_max = v.npad_max;
     eg.warm = v.warm;
+    if (!v.big.empty())
+      eg.after_init = [&](hipStream_t st) {
+        for (const BigWarm& bw : v.big) {
+          const hipError_t e0 = hipGetLastError();
+          const hipError_t e1 = hipMemcpyAsync(D(bw.Gt), D(bw.XT), (size_t)bw.Npad * bw.ld * 8, hipMemcpyDeviceToDevice, st);
+          launch_dgemm_nt64((const DgemmDesc*)D(bw.desc_off), (const BlockRef*)D(bw.map_off), bw.nblocks, st);
+          const hipError_t e2 = hipPeekAtLastError();
+          if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess)
+            fprintf(stderr, "[tadmm] big warm start (layer %d, N %d): before %s, copy %s, product %s\n", bw.layer, bw.Npad,
+                    hipGetErrorString(e0), hipGetErrorString(e1), hipGetErrorString(e2));
+        }
+      };
     int gs = 0;
     bool small_pending = false;
     const int rc = run_eig_group(h, eg, p->poll, p->jtol, p->inner, p->max_sweeps, p->debug, s, &gs, &small_pending);
@@ -517,6 +621,11 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     jac_sweeps += gs;
     launch_eig_norms(ed, (const BlockRef*)D(v.norm.map_off), v.norm.nblocks, s, sk);
     launch_eig_sort(ed, n, s, sk);
+    for (const BigWarm& bw : v.big) {
+      hipLaunchKernelGGL(bigwarm_check_kernel, dim3(1), dim3(256), 0, s, ed, bw.layer, sk, (int32_t*)D(bw.ok));
+      hipLaunchKernelGGL(bigwarm_save_kernel, dim3((bw.Npad + 3) / 4), dim3(256), 0, s, ed, bw.layer, sk,
+                         (const int32_t*)D(bw.ok), (double*)D(bw.V));
+    }
     launch_eig_extract(ed, (const BlockRef*)D(v.ext.map_off), v.ext.nblocks, s, sk);
     launch_gemm((const GemmDesc*)D(v.xg.desc_off), (const BlockRef*)D(v.xg.map_off), v.xg.nblocks, s, sk);
     return small_pending ? check_small_group(h, eg, p->poll) : TADMM_OK;
@@ -604,6 +713,8 @@ int tadmm_tucker_factors(tadmm_tucker_plan p, int layer, const float** core, con
   if (u_in) *u_in = (const float*)(p->ws + t.Ui);
   return TADMM_OK;
 }
+
+int tadmm_tucker_jacobi_sweeps(tadmm_tucker_plan p) { return p ? p->last_jacobi_sweeps : TADMM_ERR_INVALID; }
 
 int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double* errors_out_host, void* stream_) {
   DeviceGuard device_guard(p ? p->h : nullptr);

@@ -257,6 +257,10 @@ class TuckerPlan:
         self.h.check(self.h.lib.tadmm_tucker_iterations(self._plan, it, err, _stream(self.device)))
         return list(it), list(err)
 
+    def jacobi_sweeps(self) -> int:
+        """Jacobi sweeps summed over all eigen-solve groups of the last run."""
+        return int(self.h.lib.tadmm_tucker_jacobi_sweeps(self._plan))
+
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan:
             self.h.lib.tadmm_tucker_destroy(self._plan)

@@ -170,6 +170,9 @@ int tadmm_tucker_factors(tadmm_tucker_plan p, int layer, const float** core, con
 /* HOOI sweeps each layer ran in the last call and its final relative reconstruction error (host arrays of
  * n_layers entries, either may be NULL); synchronises the stream. */
 int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double* errors_out_host, void* stream);
+/* Jacobi sweeps summed over every eigen-solve group of the last run (HOSVD start + two per HOOI sweep): the figure the
+ * warm start of the HOOI solves lowers; host-side counter, no synchronisation.  Negative on a null plan. */
+int tadmm_tucker_jacobi_sweeps(tadmm_tucker_plan p);
 int tadmm_tucker_destroy(tadmm_tucker_plan p);
 
 /* ---- augmented-Lagrangian penalty (admm.py:80-85) ---------------------- */

@@ -151,3 +151,36 @@ def test_vgg16_bn_table_through_admm(dev):
     s1 = torch.linalg.svdvals(m1 @ m1.T)
     assert float(s1[r_in] / s1[0]) < 1e-9 and float(s1[r_in - 1] / s1[0]) > 1e-6
     assert 0.0 < a.logger["pre_logits.fc1.weight"][0] < float(np.linalg.norm(w["pre_logits.fc1.weight"]))
+
+
+def test_hooi_warm_start_of_streamed_solves_equals_cold(dev, monkeypatch):
+    """Streamed HOOI solves start from the previous sweep's eigenvectors (X0 = V G by one gated fp64 tile GEMM,
+    csrc/tucker_plan.hip: BigWarm): same projection, same HOOI sweep counts and errors as cold starts
+    (TADMM_TUCKER_WARM=0), fewer Jacobi sweeps; second run on the same plan starts cold again."""
+    from tadmm import ops
+    rng = np.random.default_rng(21)
+    # a 7x7 "classifier convolution" like pre_logits.fc1: the mode-0 unfolding of the projected tensor,
+    # 1280 x (49 * 30), is still 1280 wide in every HOOI sweep (a 2-D weight would shrink to N = r_in after the start)
+    shape, r = (1280, 32, 7, 7), [40, 30]
+    w0 = ((rng.standard_normal((1280, 50)) @ rng.standard_normal((50, 32 * 49))) / 7 +
+          0.2 * rng.standard_normal((1280, 32 * 49))).reshape(shape).astype(np.float32)
+
+    def run(flag):
+        monkeypatch.setenv("TADMM_TUCKER_WARM", flag)
+        w = torch.from_numpy(w0).to(dev)
+        layers = [dict(W=w, U=torch.zeros_like(w), Z=torch.zeros_like(w), ranks=r)]
+        plan = ops.TuckerPlan(layers)
+        out = []
+        for _ in range(2):
+            plan.run(update_u=True)
+            torch.cuda.synchronize()
+            out.append((layers[0]["Z"].clone(), plan.iterations(), plan.jacobi_sweeps()))
+        plan.close()
+        return out
+
+    cold, warm = run("0"), run("1")
+    for (zc, (itc, errc), jc), (zw, (itw, errw), jw) in zip(cold, warm):
+        assert itc == itw and itc[0] >= 3, (itc, itw)
+        assert float((zc - zw).abs().max()) <= 2e-6 * float(zc.abs().max())
+        assert abs(errc[0] - errw[0]) <= 1e-6
+        assert jw < jc, (jw, jc)
