@@ -122,7 +122,8 @@ void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, doub
                          const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm = false);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                       const int32_t* skip = nullptr);
-void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr);
+// npad_max: largest padded problem size of the launch (sizes the eigenvalue table in LDS; 0 = the largest supported)
+void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip = nullptr, int npad_max = 0);
 void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                         const int32_t* skip = nullptr);
 

@@ -32,6 +32,7 @@
 // converged when a whole sweep saw nothing above `tol` (Jacobi converges quadratically, so tol = 1e-9 leaves
 // ~1e-16 after that sweep) or when the quadratic-phase prediction of jacobi_conv_kernel says so.
 #include "common.h"
+#include <algorithm>
 #include <cstdio>
 
 namespace tadmm {
@@ -1416,9 +1417,9 @@ void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nbl
   if (nblocks <= 0) return;
   hipLaunchKernelGGL(eig_norms_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
-void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip) {
+void launch_eig_sort(const EigDesc* descs_dev, int nprob, hipStream_t s, const int32_t* skip, int npad_max) {
   if (nprob <= 0) return;
-  hipLaunchKernelGGL(eig_sort_kernel, dim3(nprob), dim3(256), (size_t)kJacobiMaxN * 8, s, descs_dev, skip);
+  hipLaunchKernelGGL(eig_sort_kernel, dim3(nprob), dim3(256), (size_t)std::max(2048, (npad_max > 0 && npad_max <= kJacobiMaxN) ? npad_max : kJacobiMaxN) * 8, s, descs_dev, skip);
 }
 void launch_eig_extract(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                         const int32_t* skip) {

@@ -1049,7 +1049,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
     sp.last_sweeps = gs;
     total_sweeps += gs;
     launch_eig_norms(ed, (const BlockRef*)D(sp.eig_norm.map_off), sp.eig_norm.nblocks, s, skip);
-    launch_eig_sort(ed, sp.neig, s, skip);
+    launch_eig_sort(ed, sp.neig, s, skip, sp.npad_max);
     launch_eig_extract(ed, (const BlockRef*)D(sp.eig_ext.map_off), sp.eig_ext.nblocks, s, skip);
     if (filtered) {
       if (small_pending) {
@@ -1082,7 +1082,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
         if (rc != TADMM_OK) return rc;
         total_sweeps += fgs;
         launch_eig_norms(fd, (const BlockRef*)D(fb.norm.map_off), fb.norm.nblocks, s, fskip);
-        launch_eig_sort(fd, fb.neig, s, fskip);
+        launch_eig_sort(fd, fb.neig, s, fskip, fb.npad_max);
         launch_eig_extract(fd, (const BlockRef*)D(fb.ext.map_off), fb.ext.nblocks, s, fskip);
         if (fsmall) {
           rc = check_small_group(h, fgp, p->poll);
@@ -1546,7 +1546,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   if (getenv("TADMM_STAMPS_DUMP")) { (void)hipStreamSynchronize(s); dump_stamps(); }   // -DTADMM_STAMPS builds only
   if (!conv) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in 40 sweeps");
   launch_eig_norms(edev, m_norm, (int)vn.size(), s);
-  launch_eig_sort(edev, 1, s);
+  launch_eig_sort(edev, 1, s, nullptr, Npad);
   launch_eig_extract(edev, m_ext, (int)ve.size(), s);
   // eigenvalues in descending order = sigma^2
   HIP_OK(h, hipGetLastError());

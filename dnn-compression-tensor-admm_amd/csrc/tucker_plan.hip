@@ -620,7 +620,7 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     if (rc != TADMM_OK) return rc;
     jac_sweeps += gs;
     launch_eig_norms(ed, (const BlockRef*)D(v.norm.map_off), v.norm.nblocks, s, sk);
-    launch_eig_sort(ed, n, s, sk);
+    launch_eig_sort(ed, n, s, sk, v.npad_max);
     for (const BigWarm& bw : v.big) {
       hipLaunchKernelGGL(bigwarm_check_kernel, dim3(1), dim3(256), 0, s, ed, bw.layer, sk, (int32_t*)D(bw.ok));
       hipLaunchKernelGGL(bigwarm_save_kernel, dim3((bw.Npad + 3) / 4), dim3(256), 0, s, ed, bw.layer, sk,
