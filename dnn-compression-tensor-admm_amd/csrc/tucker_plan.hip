@@ -70,6 +70,8 @@ struct Group {   // descriptors + block map of one grouped launch (offsets into 
 // rewrites the image; after the solve the normalised columns of X become the next V (bigwarm_* kernels).
 struct BigWarm {
   int layer = 0, Npad = 0, ld = 0, nblocks = 0;
+  bool apply = true;                          // false: the HOSVD start of the same mode only SAVES its eigenvectors
+                                              // (first HOOI sweep: the projected Gram has nearly the same leading ones)
   size_t V = 0, Gt = 0, XT = 0, ok = 0;      // workspace offsets: [Npad][ld] eigenvectors, G copy, the X image, int flag
   size_t desc_off = 0, map_off = 0;           // one DgemmDesc + its 64 x 64 tile map
 };
@@ -401,11 +403,13 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
         e.warm_ok = (int32_t*)dev(P->warm_ok_off) + 2 * l + (k - 2);
         v.warm = true;
       }
-      if (k >= 2 && t.bigV[k - 2]) {
+      const bool big_apply = k >= 2 && t.bigV[k - 2];
+      const bool big_save_only = k < 2 && t.bigV[k] && og[(k + 2) * n + l].N == g.N && og[(k + 2) * n + l].ld == g.ld;
+      if (big_apply || big_save_only) {
         BigWarm bw;
-        bw.layer = l; bw.Npad = g.Npad; bw.ld = g.ld;
-        bw.V = t.bigV[k - 2]; bw.Gt = t.bigG; bw.XT = t.XT;
-        bw.ok = P->warm_ok_off + (size_t)(2 * l + (k - 2)) * 4;
+        bw.layer = l; bw.Npad = g.Npad; bw.ld = g.ld; bw.apply = big_apply;
+        bw.V = t.bigV[k & 1]; bw.Gt = t.bigG; bw.XT = t.XT;
+        bw.ok = P->warm_ok_off + (size_t)(2 * l + (k & 1)) * 4;
         DgemmDesc dg;
         memset(&dg, 0, sizeof dg);
         dg.A = (const double*)dev(bw.V); dg.B = (const double*)dev(bw.Gt); dg.C = (const double*)dev(bw.XT);
@@ -605,6 +609,7 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     if (!v.big.empty())
       eg.after_init = [&](hipStream_t st) {
         for (const BigWarm& bw : v.big) {
+          if (!bw.apply) continue;
           const hipError_t e0 = hipGetLastError();
           const hipError_t e1 = hipMemcpyAsync(D(bw.Gt), D(bw.XT), (size_t)bw.Npad * bw.ld * 8, hipMemcpyDeviceToDevice, st);
           launch_dgemm_nt64((const DgemmDesc*)D(bw.desc_off), (const BlockRef*)D(bw.map_off), bw.nblocks, st);
