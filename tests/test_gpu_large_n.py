@@ -184,3 +184,25 @@ def test_hooi_warm_start_of_streamed_solves_equals_cold(dev, monkeypatch):
         assert float((zc - zw).abs().max()) <= 2e-6 * float(zc.abs().max())
         assert abs(errc[0] - errw[0]) <= 1e-6
         assert jw < jc, (jw, jc)
+
+
+def test_degenerate_big_layers_end_with_a_result(dev):
+    """All-zero and rank-1 weights beyond the resident limit: the streamed solve must end (no hang, no NaN) with
+    Z = W -- the edge cases scripts/edge_inputs.py checks for the resident kernels.  Tolerance 5e-5 relative: on EXACTLY
+    rank-deficient Grams the annihilated columns sit at the weighted convergence floor of the Jacobi solver (columns
+    with eigenvalues down to 1e-12 of the largest are kept and may lean ~1e-3 towards the genuine eigenvector), which
+    shows as 3e-7 .. 1.3e-5 relative on Z at every size, resident or streamed (scripts/edge_big.py)."""
+    from tadmm import ops
+    from tadmm._cabi import KIND_SVD
+    shape = (1408, 1600)
+    ws = [torch.zeros(shape), torch.ones(shape) * 0.25,
+          torch.outer(torch.arange(1408, dtype=torch.float32) / 1408 - 0.3, torch.ones(1600))]
+    layers = [dict(kind=KIND_SVD, W=w.to(dev), U=torch.zeros(shape, device=dev), Z=torch.empty(shape, device=dev),
+                   ranks=r) for w, r in zip(ws, (64, 300, 300))]      # 300: too large to filter -> full streamed solve
+    plan = ops.ProjectionPlan(layers)
+    resid = plan.run(update_u=True).cpu().numpy()
+    for i, (L, w) in enumerate(zip(layers, ws)):
+        z = L["Z"].cpu()
+        assert torch.isfinite(z).all()
+        assert float((z - w).norm()) <= 5e-5 * float(w.norm()) + 1e-30
+        assert abs(resid[i] - float((w - z).double().pow(2).sum())) <= 1e-5 * max(resid[i], 1e-12) + 1e-12
