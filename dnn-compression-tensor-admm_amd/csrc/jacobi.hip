@@ -1231,6 +1231,10 @@ __global__ __launch_bounds__(256) void eig_sort_kernel(const EigDesc* __restrict
   }
 }
 
+#ifndef TADMM_RESIDUE_CUT
+#define TADMM_RESIDUE_CUT 1e-12
+#endif
+constexpr double kResidueCut = TADMM_RESIDUE_CUT;     // eigenvalue (= sigma^2) below this fraction of the largest: residue
 __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restrict__ descs,
                                                           const BlockRef* __restrict__ map,
                                                           const int32_t* __restrict__ skip) {
@@ -1246,7 +1250,7 @@ __global__ __launch_bounds__(256) void eig_extract_kernel(const EigDesc* __restr
   // rounding residue -- its direction is NOT orthogonal to the genuine eigenvectors, so keeping it would count
   // their energy twice.  Such directions carry nothing (sigma <= 1e-6 sigma_max): emit a zero vector instead
   // (the reference's LAPACK pads with an arbitrary orthonormal completion; Z is unaffected).
-  if (lam <= 1e-12 * d.lam[d.order[0]]) lam = 0.0;
+  if (lam <= kResidueCut * d.lam[d.order[0]]) lam = 0.0;
   const double* row = d.XT + (int64_t)j * d.ld;
   // deterministic sign: the entry of largest magnitude (first on ties) is made positive
   double best = -1.0; int besti = 0;

@@ -188,10 +188,10 @@ def test_hooi_warm_start_of_streamed_solves_equals_cold(dev, monkeypatch):
 
 def test_degenerate_big_layers_end_with_a_result(dev):
     """All-zero and rank-1 weights beyond the resident limit: the streamed solve must end (no hang, no NaN) with
-    Z = W -- the edge cases scripts/edge_inputs.py checks for the resident kernels.  Tolerance 5e-5 relative: on EXACTLY
-    rank-deficient Grams the annihilated columns sit at the weighted convergence floor of the Jacobi solver (columns
-    with eigenvalues down to 1e-12 of the largest are kept and may lean ~1e-3 towards the genuine eigenvector), which
-    shows as 3e-7 .. 1.3e-5 relative on Z at every size, resident or streamed (scripts/edge_big.py)."""
+    Z = W -- the edge cases scripts/edge_inputs.py checks for the resident kernels.  Tolerance 5e-5 relative: constant / rank-1
+    inputs are the worst case of the fp32 accumulation in the projection and reconstruction GEMMs (all products equal,
+    every partial sum rounds the same way: K eps instead of sqrt(K) eps), 3e-7 .. 1.3e-5 at every size, resident or
+    streamed, and exactly 0 at N = 1024 (scripts/edge_big.py)."""
     from tadmm import ops
     from tadmm._cabi import KIND_SVD
     shape = (1408, 1600)
