@@ -300,3 +300,25 @@ def test_lane_split_rule_on_the_benchmark_tables():
         assert split("resnet50_tt")[0] == 1
     finally:
         del os.environ["TADMM_LANES"]
+
+
+def test_vgg16_workload_shapes_follow_the_tables():
+    """The VGG-16 Tucker tables (tk_vgg16_hp / tk_vgg16_bn_hp) key the convolutions by their `features.N` index, which
+    differs between the plain and the BN network; the synthetic workload maps the i-th table key to the i-th of
+    convolutions 2..13 and the timm-style head to a 7x7 and a 1x1 convolution.  Host logic only (no tensors built)."""
+    from tadmm import hp, workloads
+    for cfg in ("vgg16_tk", "vgg16_bn_tk"):
+        key, fmt, fn = workloads.CONFIGS[cfg]
+        assert fmt == "tk"
+        table = hp.table(key)
+        shapes = {n: fn(n) for n in table.ranks}
+        feats = [s for n, s in shapes.items() if n.startswith("features.")]
+        assert len(feats) == 12 and feats[0] == (64, 64, 3, 3) and feats[-1] == (512, 512, 3, 3)
+        assert all(a[0] <= b[0] for a, b in zip(feats, feats[1:]))                 # channel counts never shrink
+        assert shapes["pre_logits.fc1.weight"] == (4096, 512, 7, 7)
+        for n, s in shapes.items():
+            r = table.ranks[n]
+            if len(r) == 2:
+                assert r[0] <= s[0] and r[1] <= s[1], (n, r, s)                     # Tucker ranks fit their modes
+            else:
+                assert s == (4096, 4096, 1, 1) and r[0] <= 4096                     # the SVD entry of fc2
