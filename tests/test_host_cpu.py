@@ -322,3 +322,38 @@ def test_vgg16_workload_shapes_follow_the_tables():
                 assert r[0] <= s[0] and r[1] <= s[1], (n, r, s)                     # Tucker ranks fit their modes
             else:
                 assert s == (4096, 4096, 1, 1) and r[0] <= 4096                     # the SVD entry of fc2
+
+
+def test_every_workload_table_sizes_a_plan():
+    """Every rank table a synthetic workload exists for (ResNet-50/18/32, DeiT-small, VGG-16 / VGG-16-BN) passes the
+    host-side plan sizing of the C ABI with the dispatch of admm.py:47-69 -- no table is refused (the VGG tables were,
+    before the streamed Jacobi pairs).  Host logic only: no device, no tensors."""
+    import ctypes as C
+    from tadmm import _cabi, hp, workloads
+    lib = _cabi.load()
+    h = C.c_void_p()
+    lib.tadmm_create(0, C.byref(h))
+    assert h.value
+    for cfg, (key, fmt, fn) in workloads.CONFIGS.items():
+        table = hp.table(key)
+        plan_descs, tk_descs = [], []
+        for name, ranks in table.ranks.items():
+            shape = fn(name)
+            many = not isinstance(ranks, int) and len(ranks) > 1
+            if fmt == "tk" and many:
+                tk_descs.append(_cabi.make_layer_desc(_cabi.KIND_TUCKER2, shape, None, list(ranks)))
+            elif fmt == "tt" and many:
+                kind = _cabi.KIND_TT_CONV if len(shape) == 4 else _cabi.KIND_TT_LINEAR
+                plan_descs.append(_cabi.make_layer_desc(kind, shape, list(table.tt_shapes[name]), list(ranks)))
+            else:
+                plan_descs.append(_cabi.make_layer_desc(_cabi.KIND_SVD, shape, None, ranks))
+        size = C.c_size_t()
+        if plan_descs:
+            arr = (_cabi.LayerDesc * len(plan_descs))(*plan_descs)
+            rc = lib.tadmm_plan_workspace_bytes(h, len(plan_descs), arr, C.byref(size))
+            assert rc == 0 and size.value > 0, (cfg, lib.tadmm_last_error(h).decode())
+        if tk_descs:
+            arr = (_cabi.LayerDesc * len(tk_descs))(*tk_descs)
+            rc = lib.tadmm_tucker_workspace_bytes(h, len(tk_descs), arr, C.byref(size))
+            assert rc == 0 and size.value > 0, (cfg, lib.tadmm_last_error(h).decode())
+    lib.tadmm_destroy(h)
