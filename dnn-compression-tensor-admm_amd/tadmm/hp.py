@@ -53,6 +53,11 @@ def table(key: str) -> HyperParams:
     return _cache[key]
 
 
+def table_keys():
+    """Keys of every shipped rank table ('<hp file stem>.<class name>')."""
+    return sorted(_tables())
+
+
 def fresh_table(key: str) -> HyperParams:
     """An un-shared copy (tests / benchmarks that must not see earlier clamps)."""
     return HyperParams(key, _tables()[key])

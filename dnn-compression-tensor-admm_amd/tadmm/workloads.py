@@ -43,8 +43,7 @@ def resnet_cifar_shape(name: str) -> Tuple[int, ...]:
     return (p, inp, 3, 3)
 
 
-def deit_small_shape(name: str) -> Tuple[int, ...]:
-    e = 384
+def deit_small_shape(name: str, e: int = 384) -> Tuple[int, ...]:
     if name.endswith("attn.qkv.weight"):
         return (3 * e, e)
     if name.endswith("attn.proj.weight"):
@@ -87,6 +86,25 @@ CONFIGS = {
     "vgg16_bn_tk": ("tk_vgg16_bn_hp.HyperParamsDictRatio10x", "tk",
                     _vgg16_shape_fn("tk_vgg16_bn_hp.HyperParamsDictRatio10x")),
 }
+
+
+def shape_fn_for(table_key: str):
+    """Shape function of the architecture a rank table (key of data/hp_dicts.json, e.g. `tk_resnet18_hp.HyperParamsDict3x`)
+    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet, MobileNetV2)."""
+    mod = table_key.split(".")[0]
+    if "_vgg16" in mod:
+        return _vgg16_shape_fn(table_key)
+    if "_resnet18_" in mod:
+        return resnet18_shape
+    if "_resnet50_" in mod:
+        return resnet50_shape
+    if "_resnet32_" in mod or "_resnet56_" in mod:
+        return resnet_cifar_shape
+    if "_deit_small_" in mod or "_vit_small_" in mod:
+        return deit_small_shape
+    if "_deit_tiny_" in mod:
+        return lambda name: deit_small_shape(name, 192)
+    return None
 
 
 class SyntheticModel(torch.nn.Module):
