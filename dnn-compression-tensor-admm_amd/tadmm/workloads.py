@@ -90,7 +90,7 @@ CONFIGS = {
 
 def shape_fn_for(table_key: str):
     """Shape function of the architecture a rank table (key of data/hp_dicts.json, e.g. `tk_resnet18_hp.HyperParamsDict3x`)
-    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet, MobileNetV2)."""
+    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-40/121/264, MobileNetV2)."""
     mod = table_key.split(".")[0]
     if "_vgg16" in mod:
         return _vgg16_shape_fn(table_key)
@@ -104,6 +104,8 @@ def shape_fn_for(table_key: str):
         return deit_small_shape
     if "_deit_tiny_" in mod:
         return lambda name: deit_small_shape(name, 192)
+    if "_densenet201_" in mod:      # the table holds only the 3x3 `conv2` of every dense layer: growth 32, bottleneck 4 x 32
+        return lambda name: (32, 128, 3, 3)
     return None
 
 
