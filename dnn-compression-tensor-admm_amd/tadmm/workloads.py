@@ -74,6 +74,32 @@ def _vgg16_shape_fn(table_key: str):
     return fn
 
 
+def densenet_inet_shape(name: str) -> Tuple[int, ...]:
+    """DenseNet-121 / -201 (growth 32, bottleneck 4 x 32, first block at 64 channels, transitions halve): the tables hold the
+    3x3 `conv2` of the dense layers, and (121) a few 1x1 `conv1` / transition kernels."""
+    if name.endswith("conv2.weight"):
+        return (32, 128, 3, 3)
+    m = re.match(r"features\.transition(\d)\.conv\.weight", name)
+    if m:
+        c = 128 * 2 ** int(m.group(1))              # channels entering transition 1, 2, 3 of DenseNet-121
+        return (c // 2, c, 1, 1)
+    m = re.match(r"features\.denseblock(\d)\.denselayer(\d+)\.conv1\.weight", name)
+    start = {1: 64, 2: 128, 3: 256, 4: 512}[int(m.group(1))]
+    return (128, start + 32 * (int(m.group(2)) - 1), 1, 1)
+
+
+def densenet40_shape(name: str) -> Tuple[int, ...]:
+    """densenet_cifar.py:81-106,141-142: depth 40, growth 16, basic blocks (one 3x3 conv per layer, 12 per block),
+    32 channels into block 1, transitions with reduction 0.5."""
+    m = re.match(r"block(\d)\.layer\.(\d+)\.conv1\.weight", name)
+    start = {1: 32, 2: 112, 3: 152}
+    if m:
+        return (16, start[int(m.group(1))] + 16 * int(m.group(2)), 3, 3)
+    m = re.match(r"trans(\d)\.conv1\.weight", name)
+    cin = {1: 224, 2: 304}[int(m.group(1))]
+    return (cin // 2, cin, 1, 1)
+
+
 CONFIGS = {
     # name: (hp table key, format, shape function)
     "resnet50_tt": ("tt_resnet50_hp.HyperParamsDictGeneralRatio3x", "tt", resnet50_shape),
@@ -90,7 +116,7 @@ CONFIGS = {
 
 def shape_fn_for(table_key: str):
     """Shape function of the architecture a rank table (key of data/hp_dicts.json, e.g. `tk_resnet18_hp.HyperParamsDict3x`)
-    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-40/121/264, MobileNetV2)."""
+    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-264, MobileNetV2)."""
     mod = table_key.split(".")[0]
     if "_vgg16" in mod:
         return _vgg16_shape_fn(table_key)
@@ -104,8 +130,10 @@ def shape_fn_for(table_key: str):
         return deit_small_shape
     if "_deit_tiny_" in mod:
         return lambda name: deit_small_shape(name, 192)
-    if "_densenet201_" in mod:      # the table holds only the 3x3 `conv2` of every dense layer: growth 32, bottleneck 4 x 32
-        return lambda name: (32, 128, 3, 3)
+    if "_densenet201_" in mod or "_densenet121_" in mod:
+        return densenet_inet_shape
+    if "_densenet40_" in mod:
+        return densenet40_shape
     return None
 
 
