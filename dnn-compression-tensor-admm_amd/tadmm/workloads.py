@@ -88,6 +88,22 @@ def densenet_inet_shape(name: str) -> Tuple[int, ...]:
     return (128, start + 32 * (int(m.group(2)) - 1), 1, 1)
 
 
+# mobilenetv2_cifar.py:62-79: (input channels, output channels) of the 17 bottlenecks, expansion 6 (1 for the first)
+_MBV2_CIFAR = [(32, 16), (16, 24), (24, 24), (24, 32), (32, 32), (32, 32), (32, 64), (64, 64), (64, 64), (64, 64), (64, 96),
+               (96, 96), (96, 96), (96, 160), (160, 160), (160, 160), (160, 320)]
+
+
+def mobilenetv2_cifar_shape(name: str) -> Tuple[int, ...]:
+    """The 1x1 kernels of mobilenetv2_cifar.py: `bottlenecks.i.conv1` (expansion), `.conv3` (projection), final `conv1`."""
+    if name == "conv1.weight":
+        return (1280, 320, 1, 1)
+    m = re.match(r"bottlenecks\.(\d+)\.conv([13])\.weight", name)
+    i = int(m.group(1))
+    cin, cout = _MBV2_CIFAR[i]
+    c = (1 if i == 0 else 6) * cin
+    return (c, cin, 1, 1) if m.group(2) == "1" else (cout, c, 1, 1)
+
+
 def densenet40_shape(name: str) -> Tuple[int, ...]:
     """densenet_cifar.py:81-106,141-142: depth 40, growth 16, basic blocks (one 3x3 conv per layer, 12 per block),
     32 channels into block 1, transitions with reduction 0.5."""
@@ -116,7 +132,7 @@ CONFIGS = {
 
 def shape_fn_for(table_key: str):
     """Shape function of the architecture a rank table (key of data/hp_dicts.json, e.g. `tk_resnet18_hp.HyperParamsDict3x`)
-    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-264, MobileNetV2)."""
+    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-264, ImageNet MobileNetV2)."""
     mod = table_key.split(".")[0]
     if "_vgg16" in mod:
         return _vgg16_shape_fn(table_key)
@@ -134,6 +150,8 @@ def shape_fn_for(table_key: str):
         return densenet_inet_shape
     if "_densenet40_" in mod:
         return densenet40_shape
+    if "_mobilenetv2_cifar_" in mod:
+        return mobilenetv2_cifar_shape
     return None
 
 
