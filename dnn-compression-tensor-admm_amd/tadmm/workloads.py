@@ -104,6 +104,16 @@ def mobilenetv2_cifar_shape(name: str) -> Tuple[int, ...]:
     return (c, cin, 1, 1) if m.group(2) == "1" else (cout, c, 1, 1)
 
 
+def mobilenetv2_inet_shape(name: str) -> Tuple[int, ...]:
+    """ImageNet MobileNetV2 under the flat-Sequential names of the SVD table: `features.k.conv.0` (expansion) and
+    `.conv.6` (projection) of inverted residual k (same channel plan as the CIFAR model), `conv.0` = the 1280-wide head."""
+    if name == "conv.0.weight":
+        return (1280, 320, 1, 1)
+    m = re.match(r"features\.(\d+)\.conv\.([06])\.weight", name)
+    cin, cout = _MBV2_CIFAR[int(m.group(1)) - 1]
+    return (6 * cin, cin, 1, 1) if m.group(2) == "0" else (cout, 6 * cin, 1, 1)
+
+
 def densenet40_shape(name: str) -> Tuple[int, ...]:
     """densenet_cifar.py:81-106,141-142: depth 40, growth 16, basic blocks (one 3x3 conv per layer, 12 per block),
     32 channels into block 1, transitions with reduction 0.5."""
@@ -132,7 +142,7 @@ CONFIGS = {
 
 def shape_fn_for(table_key: str):
     """Shape function of the architecture a rank table (key of data/hp_dicts.json, e.g. `tk_resnet18_hp.HyperParamsDict3x`)
-    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-264, ImageNet MobileNetV2)."""
+    belongs to, or None for the families whose layer shapes are not re-derived here (DenseNet-264)."""
     mod = table_key.split(".")[0]
     if "_vgg16" in mod:
         return _vgg16_shape_fn(table_key)
@@ -152,6 +162,14 @@ def shape_fn_for(table_key: str):
         return densenet40_shape
     if "_mobilenetv2_cifar_" in mod:
         return mobilenetv2_cifar_shape
+    if mod in ("tt_mobilenetv2_hp", "tk_mobilenetv2_hp"):
+        # the TT table states every 1x1 kernel as tt_shapes [O, 1, I]; the Tucker table (timm names) lists the same 33
+        # kernels in the same order
+        tts = list(hp.table("tt_mobilenetv2_hp.HyperParamsDictRatio2x").tt_shapes.values())
+        names = list(hp.table(table_key).ranks)
+        return lambda name: (tts[names.index(name)][0], tts[names.index(name)][2], 1, 1)
+    if mod == "svd_mobilenetv2_hp":
+        return mobilenetv2_inet_shape
     return None
 
 

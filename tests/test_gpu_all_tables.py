@@ -1,5 +1,5 @@
 """One ADMM iteration (admm.py:42-78) on EVERY shipped rank table whose architecture tadmm/workloads.py re-derives
-(ResNet-18/50, ResNet-32/56, DeiT-small/tiny, ViT-small, VGG-16 / VGG-16-BN, DenseNet-40/121/201, MobileNetV2-CIFAR: 33 of the 37 tables):
+(ResNet-18/50, ResNet-32/56, DeiT-small/tiny, ViT-small, VGG-16 / VGG-16-BN, DenseNet-40/121/201, MobileNetV2 CIFAR / ImageNet: 36 of the 37 tables):
 synthetic N(0, 2/fan_in) weights, `update(update_u=False)` then `update()` (VGG: one `update()`).  Checks that hold for any projection:
 finite Z, U = W - Z, logged residual = ||W - Z||, the projection does not increase the norm (||Z|| <= ||W|| (1 + 1e-5)),
 and idempotence on one layer per table.  Tucker entries: parity UNPINNED, as everywhere."""
