@@ -251,6 +251,7 @@ struct FiltState {
   double coefk[3];            // later steps: Y_{k+1} = coefk[0]*G*Y_k + coefk[1]*Y_k + coefk[2]*Y_{k-1}
   double b, lr, l1;           // bounds used by the last stage (diagnostics)
   double crit;                // verification figure: bound on ||sin Theta||_F of the accepted subspace
+  double guard;               // power-iteration estimate of the largest eigenvalue OUTSIDE the block (filt_guard_kernel)
 };
 struct FiltProb {
   FiltState* st;
@@ -267,6 +268,7 @@ struct FiltProb {
   float* out_a; float* out_b;
   int32_t* skip_slot;                       // word of the eig group's skip array that belongs to this problem
   int32_t* fb_skip;                         // word of the fallback group's skip array: 1 = filtered result accepted
+  const double* G; int32_t ldg;             // the problem's matrix [Npad][ldg] (guard: products with single vectors)
 };
 struct FiltParams {
   int32_t max_degree;         // recurrence steps per stage (D)
@@ -276,6 +278,7 @@ struct FiltParams {
   double log_precise;         // log-amplification the fp64 stages must contribute once fp32-accuracy stages were used
 };
 void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s);
+void launch_filt_guard(const FiltProb* probs_dev, int nprob, int npad_max, int rp_max, int steps, hipStream_t s);
 // stage_fast: bit 0 = this stage's products run in dgemm3 (fp32 accuracy), bit 1 = the stage-0 product did
 void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int stage_fast, int* verdict_pinned,
                       hipStream_t s);

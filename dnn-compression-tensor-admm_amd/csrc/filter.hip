@@ -35,7 +35,7 @@ __device__ __forceinline__ double hash_unit(uint32_t a, uint32_t b) {
 
 // start block: ring[0][j][i] random for j < rp, i < N (zero in the padding); state reset
 __global__ __launch_bounds__(256) void filt_init_kernel(const FiltProb* __restrict__ probs,
-                                                        const BlockRef* __restrict__ map) {
+                                                        const BlockRef* __restrict__ map, int test_zero_col) {
   const BlockRef br = map[blockIdx.x];
   const FiltProb p = probs[br.prob];
   if (br.local == 0 && threadIdx.x == 0) {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void filt_init_kernel(const FiltProb* __restri
     st->base = 0; st->res = 1; st->nsteps = 0; st->active = 1; st->alive = 1; st->bad = 0; st->stage = 0;
     st->products = 2;       // stage-0 product + the product in front of the Rayleigh-Ritz projection
     st->products_fast = 0; st->precise_stages = 0; st->logamp_precise = 0.0;
-    st->logamp = 0.0; st->crit = 0.0; st->b = st->lr = st->l1 = 0.0;
+    st->logamp = 0.0; st->crit = 0.0; st->b = st->lr = st->l1 = 0.0; st->guard = 0.0;
     *p.skip_slot = 0;
     *p.fb_skip = 0;
   }
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void filt_init_kernel(const FiltProb* __restri
     const int64_t i = i0 + u;
     if (i < total) {
       const int col = (int)(i % p.ldy);
-      Y[i] = col < p.N ? hash_unit((uint32_t)br.prob * 2654435761u + 17u, (uint32_t)i) : 0.0;
+      // test_zero_col (TADMM_FILTER_TEST_ZERO_COL, tests only): a start block with NO component along one coordinate
+      // axis -- when that axis is an exact eigenvector the block can never acquire it (tests/test_gpu_filter.py)
+      Y[i] = (col < p.N && col != test_zero_col) ? hash_unit((uint32_t)br.prob * 2654435761u + 17u, (uint32_t)i) : 0.0;
     }
   }
 }
@@ -194,11 +196,108 @@ __global__ __launch_bounds__(256) void filt_verdict_kernel(const FiltProb* __res
   if (tid == 0) {
     const double crit = sqrt(part[0]);
     st->crit = crit;
-    const bool ok = crit <= prm.sin_tol;     // false for NaN
+    // (guard: filt_guard_kernel; 0 when the guard did not run.  NaN compares false -> rejected by the negation)
+    const double th_r = p.theta[p.r - 1];
+    const bool guard_ok = !(st->guard > th_r * (1.0 + 1e-9)) && st->guard == st->guard;
+    const bool ok = crit <= prm.sin_tol && guard_ok;     // false for NaN
     if (!ok) { st->bad = 1; st->alive = 0; }
     *p.fb_skip = ok ? 1 : 0;
     verdict[1 + blockIdx.x] = ok ? 1 : 0;
   }
+}
+
+// Independent guard of the filtered solve.  The residual-based acceptance test bounds the error of the Ritz pairs it is
+// shown; it cannot see an eigenpair the block never contained (a start block without a component along a wanted
+// eigenvector: probability zero for the hashed start on generic weights, certain for a stale warm start).  This kernel
+// looks OUTSIDE the block: a few power steps with the deflated operator P G P, P = I - Q Q^T (Q = the whole orthonormal
+// r'-block), from a start vector hashed with a different seed.  The Rayleigh quotient of a unit vector orthogonal to Q is
+// a LOWER bound of the largest eigenvalue the block does not contain; a healthy solve leaves ~lambda_{r'+1} out there,
+// well below the r-th Ritz value, so `guard > theta_r` sends the problem to the full solve (filt_verdict_kernel).
+// One 1024-thread workgroup per problem; z, w and the coefficients live in LDS.
+__global__ __launch_bounds__(1024) void filt_guard_kernel(const FiltProb* __restrict__ probs, int nsteps) {
+  extern __shared__ __attribute__((aligned(16))) double gsm[];
+  __shared__ double red[16];
+  const FiltProb p = probs[blockIdx.x];
+  FiltState* st = p.st;
+  if (st->bad) return;                                   // uniform: nobody has written yet
+  const int N = p.N, Npad = p.Npad, rp = p.rp, ldy = p.ldy, ldg = p.ldg;
+  const double* __restrict__ Q = p.ring[st->base];
+  const double* __restrict__ G = p.G;
+  double* z = gsm;
+  double* w = z + Npad;
+  double* c = w + Npad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto wave_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  auto block_sum = [&](double v) {                       // every thread gets the sum
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k];
+    return t;
+  };
+  auto project = [&](double* v) {                        // v <- (I - Q Q^T) v
+    for (int j = wave; j < rp; j += 16) {
+      const double* row = Q + (int64_t)j * ldy;
+      double a = 0.0;
+      for (int i = lane; i < N; i += 64) a += row[i] * v[i];
+      a = wave_sum(a);
+      if (lane == 0) c[j] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int j = 0;
+      for (; j + 3 < rp; j += 4) {
+        a0 += c[j] * Q[(int64_t)j * ldy + i];
+        a1 += c[j + 1] * Q[(int64_t)(j + 1) * ldy + i];
+        a2 += c[j + 2] * Q[(int64_t)(j + 2) * ldy + i];
+        a3 += c[j + 3] * Q[(int64_t)(j + 3) * ldy + i];
+      }
+      for (; j < rp; ++j) a0 += c[j] * Q[(int64_t)j * ldy + i];
+      v[i] -= (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+  };
+  for (int i = tid; i < Npad; i += 1024)
+    z[i] = i < N ? hash_unit((uint32_t)blockIdx.x * 2246822519u + 0x5bd1e995u, (uint32_t)i) : 0.0;
+  __syncthreads();
+  project(z);
+  double rho = 0.0;
+  {
+    double a = 0.0;
+    for (int i = tid; i < N; i += 1024) a += z[i] * z[i];
+    const double n2 = block_sum(a);
+    const double inv = n2 > 0.0 ? 1.0 / sqrt(n2) : 0.0;
+    for (int i = tid; i < N; i += 1024) z[i] *= inv;
+    __syncthreads();
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    for (int i = wave; i < N; i += 16) {                 // w = G z  (G symmetric: row i is contiguous)
+      const double* row = G + (int64_t)i * ldg;
+      double a = 0.0;
+      for (int k = lane; k < N; k += 64) a += row[k] * z[k];
+      a = wave_sum(a);
+      if (lane == 0) w[i] = a;
+    }
+    __syncthreads();
+    project(w);
+    double a = 0.0, b = 0.0;
+    for (int i = tid; i < N; i += 1024) { a += z[i] * w[i]; b += w[i] * w[i]; }
+    rho = fmax(rho, block_sum(a));                       // z is a unit vector orthogonal to Q
+    const double n2 = block_sum(b);
+    if (!(n2 > 0.0)) break;                              // uniform
+    const double inv = 1.0 / sqrt(n2);
+    for (int i = tid; i < N; i += 1024) z[i] = w[i] * inv;
+    __syncthreads();
+  }
+  if (tid == 0) st->guard = rho;
 }
 
 // Ritz vectors -> the outputs the projection GEMMs read (same conventions and sign rule as eig_extract_kernel)
@@ -247,7 +346,14 @@ __global__ __launch_bounds__(256) void filt_emit_kernel(const FiltProb* __restri
 
 void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(filt_init_kernel, dim3(nblocks), dim3(256), 0, s, probs_dev, map_dev);
+  int zero_col = -1;
+  if (const char* e = getenv("TADMM_FILTER_TEST_ZERO_COL")) zero_col = atoi(e);
+  hipLaunchKernelGGL(filt_init_kernel, dim3(nblocks), dim3(256), 0, s, probs_dev, map_dev, zero_col);
+}
+void launch_filt_guard(const FiltProb* probs_dev, int nprob, int npad_max, int rp_max, int steps, hipStream_t s) {
+  if (nprob <= 0 || steps <= 0) return;
+  const size_t lds = ((size_t)2 * npad_max + rp_max) * sizeof(double);
+  hipLaunchKernelGGL(filt_guard_kernel, dim3(nprob), dim3(1024), lds, s, probs_dev, steps);
 }
 void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int stage_fast, int* verdict_pinned,
                       hipStream_t s) {

@@ -20,6 +20,12 @@ static inline int filter_block_size(int N, int r) {
   return rp;
 }
 
+// power steps of the independent guard (filt_guard_kernel); TADMM_FILTER_GUARD=0 switches it off (A/B, tests)
+static inline int filter_guard_steps() {
+  if (const char* e = getenv("TADMM_FILTER_GUARD")) return std::max(0, std::min(16, atoi(e)));
+  return 4;
+}
+
 static inline int filter_tile_n() {
   const char* e = getenv("TADMM_FILTER_TN");
   return (e && atoi(e) == 64) ? 64 : 32;
@@ -45,6 +51,7 @@ struct FilterTiming {
 
 struct FilterGroup {
   int nf = 0;
+  int npad_max = 0, rp_max = 0;              // LDS of the guard kernel
   int max_degree = 8;
   size_t prob_off = 0;                       // FiltProb[nf]
   Phase init, stage0, p1, axpby, tfinal, hform, uform, verify, emit;
@@ -144,6 +151,8 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     p.sigma = sp.sigma; p.theta = (double*)dev(th_off); p.UT = (const double*)dev(ut_off);
     p.mode = sp.mode; p.ldo = sp.ldo; p.out_a = sp.out_a; p.out_b = sp.out_b;
     p.skip_slot = sp.skip_slot; p.fb_skip = sp.fb_skip;
+    p.G = sp.G; p.ldg = sp.ldg;
+    fg.npad_max = std::max(fg.npad_max, Npad); fg.rp_max = std::max(fg.rp_max, rp);
 
     auto base_desc = [&](int M, int N_, int K) {
       DgemmDesc g;
@@ -415,6 +424,7 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
   const FiltProb* probs = (const FiltProb*)D(fg.prob_off);
   const FiltParams prm = filter_params(fg);
   launch_filt_theta(probs, fg.nf, s);
+  launch_filt_guard(probs, fg.nf, fg.npad_max, fg.rp_max, filter_guard_steps(), s);
   launch_dgemm((const DgemmDesc*)D(fg.uform.desc_off), (const BlockRef*)D(fg.uform.map_off), fg.uform.nblocks, false, s);
   {
     const bool t = tm && tm->on;

@@ -76,12 +76,29 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
   const bool a_k = (d.a_cs == 1), b_k = (d.b_rs == 1) && (d.b_cs != 1);
   // For B the "rows" of the tile loader are the N index: element (n,k) at B + k*b_rs + n*b_cs
   const int K = d.K;
-  float16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Accumulation.  One fp32 MFMA accumulator over all of K rounds K times; when every product is equal (constant or
+  // rank-1 weights: all partial sums round the same way) the error grows like K eps instead of sqrt(K) eps and reached
+  // 1.3e-5 of ||W|| at K = 4608 -- above the 1e-5 parity bar.  The K range is therefore accumulated in chunks of BK = 16
+  // (8 MFMAs) into two alternating accumulators, and each finished chunk is folded into a compensated (Kahan) total
+  // on the vector ALU while the matrix pipe works on the other accumulator: error <= 16 eps inside a chunk + ~2 eps for
+  // the sum of the chunks, whatever K.
+  const float16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float16_t acc0 = zero16, acc1 = zero16, tot = zero16, cmp = zero16;
+  auto fold = [&](float16_t& a) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float y = a[e] - cmp[e];
+      const float t = tot[e] + y;
+      cmp[e] = (t - tot[e]) - y;
+      tot[e] = t;
+    }
+    a = zero16;
+  };
 
   Frag4 fa = load_tile4(d.A, d.a_rs, d.a_cs, a_k, m0, d.M, 0, K, tid);
   Frag4 fb = load_tile4(d.B, d.b_cs, d.b_rs, b_k, n0, d.N, 0, K, tid);
   const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kq = lane >> 5;
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  auto chunk = [&](int k0, float16_t& acc, float16_t& other) {
     store_tile4(As, LDA, a_k, fa, tid);
     store_tile4(Bs, LDB, b_k, fb, tid);
     __syncthreads();
@@ -95,8 +112,16 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
       const float b = Bs[(kk + kq) * LDB + bj];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    fold(other);                      // the previous chunk (its MFMAs retired an iteration ago): overlaps with this chunk's
     __syncthreads();
+  };
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    chunk(k0, acc0, acc1);
+    if (k0 + BK < K) chunk(k0 + BK, acc1, acc0);
   }
+  fold(acc0);
+  fold(acc1);
+  const float16_t acc = tot;
 
   // epilogue: D row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
   const int col = n0 + wn * 32 + (lane & 31);

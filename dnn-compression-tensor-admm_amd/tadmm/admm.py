@@ -128,6 +128,11 @@ class ADMM:
             parts = sched.latency_partition(prof, ws)
             self._parts = parts
             self._owned = parts[rk]
+            # form of the state exchange, decided ONCE from the backend (never by catching an exception around a
+            # collective: RCCL reports real failures as RuntimeError too, and ranks that disagree about which collective
+            # comes next hang): "nccl" (= RCCL) gathers one flat device buffer; every other backend (gloo: no device
+            # all-gather) gathers the list form through host staging
+            self._xchg_flat = torch.distributed.get_backend(self.process_group) == "nccl"
         self._plan = ops.ProjectionPlan([layers[i] for i in self._owned]) if self._owned else None
         # rank clamp side effect: the conv TT path clamps the shared table in place (admm.py:94,97), the
         # linear path works on a copy (admm.py:105).  The clamp is a pure function of the shapes, so every
@@ -193,12 +198,13 @@ class ADMM:
             lo = (r64 - hi.double()).float()
             send[off:off + len(mine)].copy_(hi)
             send[off + len(mine):off + 2 * len(mine)].copy_(lo)
-        recv = torch.empty(ws * mx, dtype=torch.float32, device=self.device)
-        try:
+        if self._xchg_flat:
+            recv = torch.empty(ws * mx, dtype=torch.float32, device=self.device)
             dist.all_gather_into_tensor(recv, send, group=self.process_group)
-        except (RuntimeError, NotImplementedError):      # backends without the flat form: same data, list form
-            chunks = list(recv.split(mx))
-            dist.all_gather(chunks, send, group=self.process_group)
+        else:
+            host = torch.empty(ws * mx, dtype=torch.float32)
+            dist.all_gather(list(host.split(mx)), send.cpu(), group=self.process_group)
+            recv = host.to(self.device)
         out = dict(resid)
         for owner, part in enumerate(self._parts):
             seg = recv[owner * mx:(owner + 1) * mx]

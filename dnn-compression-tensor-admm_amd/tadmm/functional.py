@@ -68,10 +68,11 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> 
 def planes_of(w: torch.Tensor, nplanes: int, pad_rows: int = 16, pad_cols: int = 32, transpose: bool = False,
               cache: dict = None, tag=None):
     """Fragment-major bf16 planes of a 2-D weight (`ops.weight_planes`).  With `cache` (a dict owned by the layer) the
-    packing is reused until the weight's version counter changes -- inference packs a layer once."""
+    packing is reused until the weight's version counter or storage address changes -- inference packs a layer once
+    (`param_key` for what that cannot see)."""
     key = None
     if cache is not None:
-        key = (tag, w._version, tuple(w.shape), nplanes, pad_rows, pad_cols, transpose)
+        key = (tag, (w._version, w.data_ptr()), tuple(w.shape), nplanes, pad_rows, pad_cols, transpose)
         hit = cache.get(key)
         if hit is not None:
             return hit
@@ -82,6 +83,36 @@ def planes_of(w: torch.Tensor, nplanes: int, pad_rows: int = 16, pad_cols: int =
             del cache[k]                                            # older versions of the same weight
         cache[key] = wp
     return wp
+
+
+def param_key(*params):
+    """Identity of a set of parameters for the inference caches: version counter AND storage address.  `p.data = t`
+    re-points the storage without touching the counter; an in-place write THROUGH `.data` (`p.data.copy_(t)`,
+    `p.data.mul_()`) changes neither -- nothing observable from the outside does -- so the layers also drop their
+    caches on `train()` / `eval()`, `_apply` (`.to()`, `.half()`) and `load_state_dict`, and expose
+    `invalidate_caches()` for callers that write through `.data` between two inference calls."""
+    return tuple((p._version, p.data_ptr()) for p in params if p is not None)
+
+
+class InferenceCacheMixin:
+    """Inference-only caches of the factorised layers (contracted factors, packed bf16 planes): see `param_key`."""
+    _CACHE_ATTRS = ("_chain_cache", "_plane_cache", "_fused_cache")
+
+    def invalidate_caches(self):
+        for a in self._CACHE_ATTRS:
+            self.__dict__.pop(a, None)
+
+    def train(self, mode: bool = True):
+        self.invalidate_caches()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_caches()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_caches()
+        return super()._load_from_state_dict(*args, **kwargs)
 
 
 def _nplanes(x: torch.Tensor) -> int:
@@ -109,9 +140,10 @@ class _ChainSingle(torch.autograd.Function):
         if not x.is_cuda:
             raise TadmmError(-1, "chain operands must live on the HIP device (no CPU fallback)")
         image = x.dim() == 4
-        if wp is None:
+        fresh = wp is None                          # planes packed for this call only: keep them out of the launch memo
+        if fresh:
             wp = planes_of(w, _nplanes(x))
-        y = ops.chain_single(x, wp, bias, w.shape[0], entry=entry, image_out=image)
+        y = ops.chain_single(x, wp, bias, w.shape[0], entry=entry, image_out=image, memo=not fresh)
         ctx.save_for_backward(x, w)
         ctx.entry, ctx.has_bias, ctx.image = entry, bias is not None, image
         return y
@@ -123,7 +155,7 @@ class _ChainSingle(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:                 # dX = dY W : the same kernel with the transposed weight
             gx = ops.chain_single(g, planes_of(w, _nplanes(g), transpose=True), None, w.shape[1], entry=ctx.entry,
-                                  image_out=ctx.image)
+                                  image_out=ctx.image, memo=False)
         if ctx.needs_input_grad[1]:                 # dW = dY^T X  (N x K), plain fp32 product
             if ctx.image:
                 g2 = g.permute(1, 0, 2, 3).reshape(g.shape[1], -1)
@@ -142,12 +174,14 @@ def pointwise(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None, entry
     (the 1x1 convolutions of TKConv.py:93-98 and the core chains of TTConv.py:131-151).  Differentiable.  `planes`:
     prebuilt `planes_of(w, ...)` (inference caches)."""
     if not _needs_grad(x, w, bias):                   # inference: straight to the C ABI, no autograd node
-        if planes is None:
+        fresh = planes is None
+        if fresh:
             planes = planes_of(w, _nplanes(x))
         if x.dim() == 4:
-            return ops.chain_single(x, planes, bias, w.shape[0], entry=entry, image_out=True)
+            return ops.chain_single(x, planes, bias, w.shape[0], entry=entry, image_out=True, memo=not fresh)
         lead = x.shape[:-1]
-        return ops.chain_single(x.reshape(-1, x.shape[-1]), planes, bias, w.shape[0], entry=entry).reshape(*lead, w.shape[0])
+        return ops.chain_single(x.reshape(-1, x.shape[-1]), planes, bias, w.shape[0], entry=entry,
+                                memo=not fresh).reshape(*lead, w.shape[0])
     if x.dim() == 4:
         return _ChainSingle.apply(x.contiguous(), w, bias, entry, planes)
     lead = x.shape[:-1]
@@ -162,9 +196,10 @@ class _ChainFused(torch.autograd.Function):
         if not x.is_cuda:
             raise TadmmError(-1, "chain operands must live on the HIP device (no CPU fallback)")
         n = _nplanes(x)
-        if planes is None:
+        fresh = planes is None
+        if fresh:
             planes = (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))
-        y = ops.chain_fused(x, planes[0], planes[1], bias, w_out.shape[0])
+        y = ops.chain_fused(x, planes[0], planes[1], bias, w_out.shape[0], memo=not fresh)
         ctx.save_for_backward(x, w_in, w_out)
         ctx.has_bias = bias is not None
         return y
@@ -178,12 +213,12 @@ class _ChainFused(torch.autograd.Function):
         if ctx.needs_input_grad[0]:                 # dX = (dY Wout) Win: the fused kernel on the transposed factors
             gx = ops.chain_fused(g, planes_of(w_out, n, pad_rows=64, transpose=True),
                                  planes_of(w_in, n, pad_cols=64, transpose=True), None, w_in.shape[1],
-                                 entry="tadmm_ttlinear_bwd")
+                                 entry="tadmm_ttlinear_bwd", memo=False)
         if ctx.needs_input_grad[1]:                 # dWin = (dY Wout)^T X
-            gr = ops.chain_single(g, planes_of(w_out, n, transpose=True), None, w_out.shape[1])
+            gr = ops.chain_single(g, planes_of(w_out, n, transpose=True), None, w_out.shape[1], memo=False)
             gwi = ops.mm(_as_gemm_operand(gr.float()).t(), _as_gemm_operand(x.float()))
         if ctx.needs_input_grad[2]:                 # dWout = dY^T (X Win^T)
-            h = ops.chain_single(x, planes_of(w_in, _nplanes(x)), None, w_in.shape[0])
+            h = ops.chain_single(x, planes_of(w_in, _nplanes(x)), None, w_in.shape[0], memo=False)
             gwo = ops.mm(_as_gemm_operand(g.float()).t(), _as_gemm_operand(h.float()))
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = g.sum(0)
@@ -196,9 +231,10 @@ def linear_chain(x: torch.Tensor, w_in: torch.Tensor, w_out: torch.Tensor, bias:
     (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))."""
     lead = x.shape[:-1]
     if not _needs_grad(x, w_in, w_out, bias):         # inference: straight to the C ABI, no autograd node
-        if planes is None:
+        fresh = planes is None
+        if fresh:
             n = _nplanes(x)
             planes = (planes_of(w_in, n, pad_rows=64), planes_of(w_out, n, pad_cols=64))
-        return ops.chain_fused(x.reshape(-1, x.shape[-1]), planes[0], planes[1], bias, w_out.shape[0]).reshape(
-            *lead, w_out.shape[0])
+        return ops.chain_fused(x.reshape(-1, x.shape[-1]), planes[0], planes[1], bias, w_out.shape[0],
+                               memo=not fresh).reshape(*lead, w_out.shape[0])
     return _ChainFused.apply(x.reshape(-1, x.shape[-1]), w_in, w_out, bias, planes).reshape(*lead, w_out.shape[0])

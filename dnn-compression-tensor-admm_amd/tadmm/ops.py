@@ -5,6 +5,7 @@ to libtadmm_hip.so on the current HIP stream.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -364,11 +365,30 @@ def unpack_planes(wp: torch.Tensor) -> torch.Tensor:
     return wp.view(P, nt, ks, 4, 16, 8).permute(0, 1, 4, 2, 3, 5).reshape(P, nt * 16, ks * 32)
 
 
-_CHAIN_MEMO = {}
+class _LruMemo(collections.OrderedDict):
+    """Validated descriptors of recent chain launches, keyed on geometry + weight-plane addresses.  An entry pins its
+    plane tensors (that is what keeps the addresses meaningful), so the memo is a small LRU: callers whose planes are
+    short-lived (the autograd Functions pack fresh planes every call) pass `memo=False` and never enter it."""
+    CAP = 128
+
+    def lookup(self, key):
+        hit = self.get(key)
+        if hit is not None:
+            self.move_to_end(key)
+        return hit
+
+    def store(self, key, value):
+        self[key] = value
+        self.move_to_end(key)
+        while len(self) > self.CAP:
+            self.popitem(last=False)
+
+
+_CHAIN_MEMO = _LruMemo()
 
 
 def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin: int, n1: int, n_out: int,
-                image_out: bool, tile_tokens: int, prepare_only: bool = False):
+                image_out: bool, tile_tokens: int, prepare_only: bool = False, use_memo: bool = True):
     if not x.is_cuda:
         raise TadmmError(-1, "x must live on a HIP device; there is no CPU path")
     if x.dim() == 4:                                   # (B, C, H, W) read in place
@@ -381,10 +401,12 @@ def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin:
         bias_key = None                                 # a converted copy: nothing to memoise
     else:
         bias_key = 0 if bias is None else bias.data_ptr()
+    if not use_memo:
+        bias_key = None                                 # short-lived planes (training): build, launch, forget
     # geometry + weight identity -> validated descriptor; only the activation pointers change between calls
     key = (entry, tuple(x.shape), x.stride(0), x.dtype, x.device, win.data_ptr(), 0 if wout is None else wout.data_ptr(),
            bias_key, kin, n1, n_out, image_out, tile_tokens)
-    memo = _CHAIN_MEMO.get(key) if bias_key is not None else None
+    memo = _CHAIN_MEMO.lookup(key) if bias_key is not None else None
     if memo is None:
         if x.dtype == torch.float32:
             dtype, planes = _cabi.CHAIN_F32, 3
@@ -430,9 +452,7 @@ def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin:
         h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
         memo = (d, getattr(h.lib, entry), h, yshape, T, (win, wout, bias))     # the tuple keeps the weights alive
         if bias_key is not None:
-            if len(_CHAIN_MEMO) >= 1024:
-                _CHAIN_MEMO.clear()
-            _CHAIN_MEMO[key] = memo
+            _CHAIN_MEMO.store(key, memo)
     d, fn, h, yshape, T, _ = memo
     y = torch.empty(yshape, dtype=x.dtype, device=x.device)
 
@@ -448,20 +468,20 @@ def _chain_call(entry: str, x: torch.Tensor, win: torch.Tensor, wout, bias, kin:
 
 
 def chain_fused(x, win_planes, wout_planes, bias, n_out: int, entry: str = "tadmm_ttlinear_fwd", tile_tokens: int = 0,
-                prepare_only: bool = False):
+                prepare_only: bool = False, memo: bool = True):
     """y (T, n_out) = (x (T, Kin) @ Win^T) @ Wout^T + bias in one launch (TTLinear.py:75-93).  `win_planes` (rows
     padded to the middle rank R, a multiple of 64, <= 256) and `wout_planes` come from `weight_planes`."""
     return _chain_call(entry, x, win_planes, wout_planes, bias, x.shape[-1], win_planes.shape[1] * 16, n_out, False,
-                       tile_tokens, prepare_only)
+                       tile_tokens, prepare_only, memo)
 
 
 def chain_single(x, w_planes, bias, n_out: int, entry: str = "tadmm_ttconv_chain_in", image_out: bool = False,
-                 tile_tokens: int = 0, prepare_only: bool = False):
+                 tile_tokens: int = 0, prepare_only: bool = False, memo: bool = True):
     """y = x @ W^T + bias for token rows (T, Kin) or, in place, a channels-first image (B, Kin, H, W) ->
     (B, n_out, H, W) when `image_out` (TTConv.py:131-137 / :141-151, TKConv.py:93-98).  `prepare_only` returns a
     zero-argument launcher over the same buffers (benchmarks: no per-call descriptor building)."""
     kin = x.shape[1]
-    return _chain_call(entry, x, w_planes, None, bias, kin, n_out, 0, image_out, tile_tokens, prepare_only)
+    return _chain_call(entry, x, w_planes, None, bias, kin, n_out, 0, image_out, tile_tokens, prepare_only, memo)
 
 
 def _conv_chain_plan(x: torch.Tensor, r1: int, r2: int, kernel_size, stride, padding, dilation):
@@ -537,7 +557,7 @@ def conv_chain(x: torch.Tensor, w1p: torch.Tensor, w2p: torch.Tensor, w3p: torch
         bias_key = 0 if bias is None else bias.data_ptr()
     key = ("conv", tuple(x.shape), x.dtype, x.device, w1p.data_ptr(), w2p.data_ptr(), w3p.data_ptr(), bias_key, n_out,
            tuple(kernel_size), tuple(stride), tuple(padding), tuple(dilation))
-    memo = _CHAIN_MEMO.get(key) if bias_key is not None else None
+    memo = _CHAIN_MEMO.lookup(key) if bias_key is not None else None
     if memo is None:
         B, Cc, H, W = x.shape
         d = _cabi.ConvChainDesc()
@@ -558,9 +578,7 @@ def conv_chain(x: torch.Tensor, w1p: torch.Tensor, w2p: torch.Tensor, w3p: torch
         h = Handle.get(dev.index if dev.index is not None else torch.cuda.current_device())
         memo = (d, h.lib.tadmm_ttconv_fused, h, (B, n_out, ho, wo), (w1p, w2p, w3p, bias))
         if bias_key is not None:
-            if len(_CHAIN_MEMO) >= 1024:
-                _CHAIN_MEMO.clear()
-            _CHAIN_MEMO[key] = memo
+            _CHAIN_MEMO.store(key, memo)
     d, fn, h, yshape, _ = memo
     y = torch.empty(yshape, dtype=x.dtype, device=x.device)
     d.X, d.Y = x.data_ptr(), y.data_ptr()

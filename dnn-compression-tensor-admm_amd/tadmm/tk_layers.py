@@ -46,7 +46,7 @@ def _recover(core: Tensor, last_factor: Tensor, first_factor: Tensor) -> Tensor:
     return t.reshape(o, rest, -1).permute(0, 2, 1).reshape(o, first_factor.shape[1], *core.shape[2:])
 
 
-class _TKConvBase(nn.Module):
+class _TKConvBase(HF.InferenceCacheMixin, nn.Module):
     def _setup(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, padding_mode, ranks):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.ranks = ranks
@@ -122,7 +122,7 @@ class TKConv2dC(_TKConvBase):
             return None
         n = 1 if x.dtype == torch.bfloat16 else 3
         cache = self.__dict__.setdefault("_fused_cache", {})
-        key = (n, x.device, w1._version, core._version, w3._version)
+        key = (n, x.device, HF.param_key(w1, core, w3))
         if cache.get("key") != key:
             cache.update(key=key, planes=(ops.weight_planes(w1.detach(), n, pad_rows=32), ops.conv_core_planes(core, n),
                                           ops.weight_planes(w3.detach(), n)))
@@ -251,7 +251,7 @@ class TKConv2dR(_TKConvBase):
         return self._conv_forward(x, self._recover_weight())
 
 
-class _TKLinearBase(nn.Module):
+class _TKLinearBase(HF.InferenceCacheMixin, nn.Module):
     def __init__(self, in_features: int, out_features: int, bias: bool = True, hp_dict=None, name: str = None,
                  dense_w: Tensor = None, dense_b: Tensor = None) -> None:
         super().__init__()
@@ -289,9 +289,11 @@ class TKLinearM(_TKLinearBase):
         launch of the fused chain (`tadmm_ttlinear_fwd`: y = last (core first) x + bias, the out_rank-vector of a token in
         LDS) whenever out_rank fits it; otherwise three strided GEMMs."""
         align = 8 if x.dtype == torch.bfloat16 else 4
+        params = (self.first_factor, self.core_tensor, self.last_factor)
+        # (the backward runs the fused kernel with the gradient as X: its row length out_features must be aligned too)
         if (x.dtype in (torch.float32, torch.bfloat16) and HF.fused_rank_ok(self.out_rank) and x.is_cuda
-                and self.in_features % align == 0):
-            params = (self.first_factor, self.core_tensor, self.last_factor)
+                and self.in_features % align == 0
+                and (self.out_features % align == 0 or not HF._needs_grad(x, self.bias, *params))):
             grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
             if grad and x.dtype == torch.float32:
                 w_in = HF.mm(self.core_tensor, self.first_factor)             # (out_rank, in_features), differentiable
@@ -299,7 +301,7 @@ class TKLinearM(_TKLinearBase):
             if not grad:
                 n = 1 if x.dtype == torch.bfloat16 else 3
                 cache = self.__dict__.setdefault("_chain_cache", {})
-                key = (n, x.device, tuple(p._version for p in params))
+                key = (n, x.device, HF.param_key(*params))
                 if cache.get("key") != key:
                     with torch.no_grad():
                         w_in = HF.mm(self.core_tensor, self.first_factor)

@@ -70,7 +70,7 @@ def _decompose(dense_w: Tensor, tt_shapes, tt_ranks, kind):
     return cores
 
 
-class _TTConvBase(nn.Module):
+class _TTConvBase(HF.InferenceCacheMixin, nn.Module):
     def _setup(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, padding_mode,
                hp_dict, name):
         self.tt_shapes = list(hp_dict.tt_shapes[name])
@@ -181,14 +181,17 @@ class TTConv2dM(_TTConvBase):
             p_in = p_out = None
         else:
             cache = self.__dict__.setdefault("_chain_cache", {})
-            key = (n, x.device, tuple(p._version for p in params), self.core_kernel._version)
+            key = (n, x.device, HF.param_key(*params, self.core_kernel))
             if cache.get("key") != key:
                 with torch.no_grad():
                     w_in, w_out = self._factors()
                 cache.update(key=key, w=(w_in, w_out), planes=(HF.planes_of(w_in, n), HF.planes_of(w_out, n)))
             (w_in, w_out), (p_in, p_out) = cache["w"], cache["planes"]
-        if not grad and self.groups == 1 and ops.conv_chain_pays(x, w_in.shape[0], w_out.shape[1], self.kernel_size,
-                                                                  self.stride, self.padding, self.dilation):
+        # the one-launch path builds no autograd node: only when NOTHING it reads wants a gradient (frozen cores with a
+        # trainable input / core kernel / bias keep the three differentiable launches below)
+        if (not grad and not HF._needs_grad(x, self.core_kernel, self.bias) and self.groups == 1
+                and ops.conv_chain_pays(x, w_in.shape[0], w_out.shape[1], self.kernel_size, self.stride, self.padding,
+                                        self.dilation)):
             # small planes (<= 64 pixels): the whole layer in ONE launch, both intermediates in LDS (csrc/convchain.hip)
             fkey = (key, "fused")
             if cache.get("fkey") != fkey:
@@ -291,7 +294,7 @@ class TTConv2dR(_TTConvBase):
         return self._conv_forward(x, self._recover_weight())
 
 
-class _TTLinearBase(nn.Module):
+class _TTLinearBase(HF.InferenceCacheMixin, nn.Module):
     def __init__(self, in_features: int, out_features: int, bias: bool = True, hp_dict=None, name: str = None,
                  dense_w: Tensor = None, dense_b: Tensor = None):
         super().__init__()
@@ -338,8 +341,12 @@ class TTLinearM(_TTLinearBase):
     def _fused_ok(self, x):
         q = self.out_tt_order
         align = 8 if x.dtype == torch.bfloat16 else 4
-        return (x.dtype in (torch.float32, torch.bfloat16) and 0 < q < self.tt_order
-                and HF.fused_rank_ok(self.tt_ranks[q]) and self.in_features % align == 0)
+        if not (x.dtype in (torch.float32, torch.bfloat16) and 0 < q < self.tt_order
+                and HF.fused_rank_ok(self.tt_ranks[q]) and self.in_features % align == 0):
+            return False
+        # the backward runs the same kernels with the gradient as X (row length out_features): a head whose width is
+        # not 16-byte aligned (10 classes) trains through the per-core chain instead
+        return self.out_features % align == 0 or not HF._needs_grad(x, self.bias, *self.tt_cores)
 
     def forward(self, x):
         """TTLinear.py:75-93.  One launch (`tadmm_ttlinear_fwd`) when the middle rank fits the fused kernel: the
@@ -353,7 +360,7 @@ class TTLinearM(_TTLinearBase):
             if not grad:
                 n = 1 if x.dtype == torch.bfloat16 else 3
                 cache = self.__dict__.setdefault("_chain_cache", {})
-                key = (n, x.device, tuple(p._version for p in self.tt_cores))
+                key = (n, x.device, HF.param_key(*self.tt_cores))
                 if cache.get("key") != key:
                     with torch.no_grad():
                         w_in, w_out = self._factors()

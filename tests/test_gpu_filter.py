@@ -127,6 +127,51 @@ def test_low_rank_input_falls_back_to_the_full_solve(dev, monkeypatch):
     assert np.linalg.norm(zf[0] - ws[1]) <= 2e-6 * np.linalg.norm(ws[1])
 
 
+def test_guard_catches_an_eigenvector_the_block_never_contained(dev, monkeypatch):
+    """The a-posteriori residual check only sees the Ritz pairs it is shown.  Plant a DOMINANT eigenvector the block can
+    never acquire: column k of the unfolding is supported on one row where every other column is zero, so e_k is an
+    exact eigenvector of the Gram matrix (G[k][j] = 0 exactly), and the test hook TADMM_FILTER_TEST_ZERO_COL starts the
+    block with no component along e_k -- products with G keep that component exactly zero.  Without the guard the
+    filtered solve passes its verification and returns a Z that misses the largest singular direction; the guard
+    (power steps on the deflated operator, csrc/filter.hip: filt_guard_kernel) must send the problem to the full solve."""
+    from tadmm import ops
+    from tadmm._cabi import KIND_TT_CONV
+    rng = np.random.default_rng(11)
+    shape, tts, ranks, k = (1024, 256, 1, 1), [1024, 1, 256], [1, 75, 75, 1], 37
+    a = (rng.standard_normal((1024, 256)) * np.sqrt(2.0 / 256)).astype(np.float32)
+    a[0, :] = 0.0
+    a[:, k] = 0.0
+    a[0, k] = 25.0                                   # sigma_1 = 25, far above the bulk (~3): the dominant direction
+    w = a.reshape(shape)
+    ref = O.prune_conv_rank_tt(w, tts, list(ranks))
+    assert abs(ref[0, k, 0, 0] - 25.0) < 1e-3
+
+    def run(zero_col, guard):
+        monkeypatch.setenv("TADMM_FILTER", "1")
+        monkeypatch.setenv("TADMM_FILTER_GUARD", guard)
+        if zero_col is None:
+            monkeypatch.delenv("TADMM_FILTER_TEST_ZERO_COL", raising=False)
+        else:
+            monkeypatch.setenv("TADMM_FILTER_TEST_ZERO_COL", str(zero_col))
+        t = torch.from_numpy(w).to(dev)
+        L = dict(kind=KIND_TT_CONV, W=t, U=torch.zeros_like(t), Z=torch.empty_like(t), tt_shapes=tts, ranks=list(ranks))
+        plan = ops.ProjectionPlan([L])
+        plan.run(update_u=False, use_u=False)
+        st = plan.filter_stats()
+        plan.close()
+        return L["Z"].cpu().numpy(), st
+
+    z_ok, st_ok = run(None, "4")                     # healthy start block: no fallback, guard silent
+    assert st_ok["eligible"] == 1 and st_ok["fallbacks"] == 0, st_ok
+    assert np.linalg.norm(z_ok - ref) <= 1e-5 * np.linalg.norm(ref)
+    z_blind, st_blind = run(k, "0")                  # guard off: the planted failure is real and goes unnoticed
+    assert st_blind["fallbacks"] == 0, st_blind
+    assert abs(z_blind[0, k, 0, 0]) < 1.0 and np.linalg.norm(z_blind - ref) > 0.5 * np.linalg.norm(ref)
+    z_g, st_g = run(k, "4")                          # guard on: rejected, full solve, right answer
+    assert st_g["fallbacks"] == 1, st_g
+    assert np.linalg.norm(z_g - ref) <= 1e-5 * np.linalg.norm(ref)
+
+
 def test_filtered_cores_match_full_solve(dev, monkeypatch):
     """want_cores (ten2tt / --decompose): individual Ritz vectors, not only their span, must agree with the full
     solve; compared through the gauge-invariant reconstruction and the singular values."""

@@ -188,10 +188,10 @@ def test_hooi_warm_start_of_streamed_solves_equals_cold(dev, monkeypatch):
 
 def test_degenerate_big_layers_end_with_a_result(dev):
     """All-zero and rank-1 weights beyond the resident limit: the streamed solve must end (no hang, no NaN) with
-    Z = W -- the edge cases scripts/edge_inputs.py checks for the resident kernels.  Tolerance 5e-5 relative: constant / rank-1
-    inputs are the worst case of the fp32 accumulation in the projection and reconstruction GEMMs (all products equal,
-    every partial sum rounds the same way: K eps instead of sqrt(K) eps), 3e-7 .. 1.3e-5 at every size, resident or
-    streamed, and exactly 0 at N = 1024 (scripts/edge_big.py)."""
+    Z = W -- the edge cases scripts/edge_inputs.py checks for the resident kernels.  Tolerance 1e-5 relative (north_star's
+    bar): constant / rank-1 inputs are the worst case of fp32 accumulation in the projection and reconstruction GEMMs (all
+    products equal, every partial sum rounds the same way: K eps instead of sqrt(K) eps -- up to 1.3e-5 in round 2); since
+    round 3 `gemm_kernel` accumulates K in chunks of 16 folded into a compensated total (csrc/gemm.hip)."""
     from tadmm import ops
     from tadmm._cabi import KIND_SVD
     shape = (1408, 1600)
@@ -204,5 +204,5 @@ def test_degenerate_big_layers_end_with_a_result(dev):
     for i, (L, w) in enumerate(zip(layers, ws)):
         z = L["Z"].cpu()
         assert torch.isfinite(z).all()
-        assert float((z - w).norm()) <= 5e-5 * float(w.norm()) + 1e-30
+        assert float((z - w).norm()) <= 1e-5 * float(w.norm()) + 1e-30
         assert abs(resid[i] - float((w - z).double().pow(2).sum())) <= 1e-5 * max(resid[i], 1e-12) + 1e-12
