@@ -102,7 +102,8 @@ def cpu_baseline(config, max_seconds=30.0):
         from threadpoolctl import threadpool_limits
     except Exception:
         threadpool_limits = None
-    candidates = [c for c in (16, 8, 32, ncpu) if c <= ncpu] or [ncpu]
+    # (the <= 64-column SVDs of the Tucker table are too small to thread: try 1 and 4 as well)
+    candidates = [c for c in ((1, 4, 16) if fmt == "tk" else (16, 8, 32, ncpu)) if c <= ncpu] or [ncpu]
     seen = set()
     for th in candidates:
         if th in seen or (time.perf_counter() - t_start) > max_seconds:
@@ -128,10 +129,218 @@ def cpu_baseline(config, max_seconds=30.0):
                 seconds_per_sweep=best, seconds_by_threads={str(k): v for k, v in tried.items()})
 
 
+def load_pmc_traffic(config):
+    """Newest committed PMC pass of this configuration (profiles/r*_pmc_traffic*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; bench.py cannot run rocprofv3 itself).
+    -> (kernels dict, meta dict)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("config", "resnet50_tt") == config:
+            best = (f, d)                      # sorted by name: the latest round wins
+    if best is None:
+        return {}, {}
+    f, d = best
+    return d.get("kernels", {}), {"file": os.path.relpath(f, ROOT), "commit": d.get("commit", "unknown (pass predates provenance)"),
+                                  "plan_runs_in_pass": d.get("plan_runs_in_pass")}
+
+
+def pmc_traffic_for(pm, meta, kernel, launches_per_step, world):
+    """HBM bytes per launch of `kernel` from the committed PMC pass -- only if that pass ran the same number of launches per
+    step as this run (+-10 %): a figure from another binary / another schedule is dropped (null + reason), not stamped on."""
+    k = pm.get(kernel)
+    if not k or world != 1:
+        return None, (None if world == 1 else "single-GPU PMC pass only")
+    lps = k.get("launches_per_step")
+    if lps is None:
+        return None, f"{meta.get('file')}: pass predates launch-count provenance; dropped"
+    if abs(lps - launches_per_step) > 0.10 * max(lps, launches_per_step):
+        return None, (f"{meta.get('file')} (commit {meta.get('commit')}): {lps:.0f} launches per step in the PMC pass vs "
+                      f"{launches_per_step:.0f} in this run (> 10 % apart); dropped")
+    return k.get("hbm_bytes_per_launch_corrected"), (f"{meta.get('file')} (commit {meta.get('commit')}, {lps:.0f} launches per "
+                                                     f"step in the pass, {launches_per_step:.0f} here)")
+
+
+def tucker_flops(shape, ranks, sweeps):
+    """Dense-contraction FLOPs of one Tucker-2 projection (HOSVD Grams + `sweeps` HOOI sweeps + Z), and the 8 N^3 model of
+    its eigen-solves: dict(mfma=.., eig=..).  admm.py:113-127 -> tensorly partial_tucker."""
+    O, I = int(shape[0]), int(shape[1])
+    k2 = 1
+    for d in shape[2:]:
+        k2 *= int(d)
+    ro, ri = min(int(ranks[0]), O), min(int(ranks[1]), I)
+
+    def gram(m, n):
+        return 2.0 * max(m, n) * min(m, n) ** 2
+
+    def eig(m, n):
+        return 8.0 * min(m, n) ** 3
+    hosvd = gram(O, I * k2) + gram(I, O * k2)
+    per = 2.0 * O * k2 * I * ri + gram(O, k2 * ri) + 2.0 * I * k2 * O * ro + gram(I, k2 * ro) + 2.0 * ro * k2 * I * ri
+    final = 2.0 * ro * k2 * ri * I + 2.0 * O * ro * k2 * I
+    eigs = eig(O, I * k2) + eig(I, O * k2) + sweeps * (eig(O, k2 * ri) + eig(I, k2 * ro))
+    return dict(mfma=hosvd + sweeps * per + final, eig=eigs, numel=O * I * k2)
+
+
+def bench_tucker(args):
+    """`--config resnet32_tk` (BASELINE config 2): the 'tk' branch of ADMM.update for the whole table -- one grouped
+    HOSVD + HOOI plan on the device (csrc/tucker_plan.hip) -- same JSON schema as the TT configurations.
+    PARITY UNPINNED for this branch (tensorly absent, no reference fixtures): DESIGN.md 3."""
+    import numpy as np
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per requested GPU")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % ndev)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ndev >= world:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tadmm import ops, sched, workloads
+    model, hp, fmt = workloads.build(args.config, seed=0)
+    names, layers = [], []
+    for name, p in model.named_parameters():
+        if name in hp.ranks:
+            w = p.data.to(dev).contiguous()
+            layers.append(dict(W=w, U=torch.zeros_like(w), Z=torch.empty_like(w), ranks=list(hp.ranks[name])))
+            names.append(name)
+    # layers are independent units (admm.py:43): LPT on the one-sweep contraction cost; no data-path collective
+    parts = sched.lpt_partition([tucker_flops(L["W"].shape, L["ranks"], 3)["mfma"] for L in layers], world)
+    mine = parts[rank]
+    plan = ops.TuckerPlan([layers[i] for i in mine]) if mine else None
+    total_resid = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if plan is not None:
+            total_resid.copy_(plan.run(update_u=True).sum().reshape(1))
+        else:
+            total_resid.zero_()
+        if dist is not None:
+            dist.all_reduce(total_resid)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+    ms_per_step = 1e3 * el / args.steps
+    its, errs = plan.iterations() if plan is not None else ([], [])
+    fl = [tucker_flops(layers[i]["W"].shape, layers[i]["ranks"], its[j]) for j, i in enumerate(mine)]
+    mfma_able = sum(f["mfma"] for f in fl)
+    out = {
+        "metric": "ADMM projection iters/sec (all layers) + per-layer SVD GFLOP/s, ResNet-50 TT ranks",
+        "value": args.steps / el, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
+        "vs_baseline": None, "dtype": "f32 (Gram and eigen-solve in f64)", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {len(layers)} layers, {sum(f['numel'] for f in fl)} weights on rank 0, "
+                               f"hp table {workloads.CONFIGS[args.config][0]} (Tucker-2: HOSVD + HOOI, tol 1e-4, <= 100 sweeps)",
+                   "tables": 1, "layers_per_rank": [len(p) for p in parts],
+                   "parallelism": f"layer-shard x{world} (LPT, one scalar all-reduce per step)"},
+        "parity": "UNPINNED for the Tucker branch: tensorly is absent and the reference holds no fixtures (DESIGN.md 3); "
+                  "device == the oracle's float64 restatement <= 5e-5 with identical HOOI sweep counts",
+        "hooi_sweeps": {"max": max(its) if its else 0, "per_layer": its},
+        "residual_sq": float(total_resid[0]),
+    }
+    out["roofline_sweep"] = {"bound": "mfma", "achieved": mfma_able / (ms_per_step * 1e-3) / 1e12,
+                             "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                             "frac": mfma_able / (ms_per_step * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                             "note": "Gram + mode-product FLOPs of HOSVD, the HOOI sweeps each layer actually ran and Z / "
+                                     "ms_per_step / fp32 MFMA peak; 0.46 M weights: the configuration is launch- and "
+                                     "latency-bound (SURVEY 8d config 2)"}
+    if rank == 0 and plan is not None and not args.no_roofline:
+        plan.enable_timing(True)
+        reps, acc = max(3, min(args.steps, 10)), None
+        for _ in range(reps):
+            plan.run(update_u=True)
+            t = plan.last_timing()
+            acc = t if acc is None else {k: acc[k] + t[k] for k in t}
+        plan.enable_timing(False)
+        eig_ms, nl = acc["eig_ms"] / reps, acc["eig_launches"] / reps
+        tf = acc["eig_model_flops"] / (acc["eig_ms"] * 1e-3) / 1e12 if acc["eig_ms"] > 0 else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "single-launch symmetric eigen-solver of the <= 64-column Gram matrices (one workgroup per "
+                                       "problem; csrc/jacobi.hip / csrc/tridiag.hip)",
+            "achieved": tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F64_MFMA_TFLOPS,
+            "traffic": None, "traffic_note": "no PMC pass for this configuration (the problems live in LDS: 30 x 32 KiB per launch)",
+            "launches_per_step": nl, "avg_launch_us": 1e3 * eig_ms / max(1.0, nl),
+            "time_share": eig_ms / max(1e-9, acc["total_ms"] / reps),
+            "flops_per_step": acc["eig_model_flops"] / reps,
+            "note": "achieved = 8 N^3 model of a full symmetric eigen-decomposition, summed over the problems of a launch / "
+                    "HIP-event time of the launch on the launch stream.  The launches are latency-bound (30 workgroups on 256 "
+                    "CUs, a dependent chain inside each): the fraction says how little of the chip the configuration can use"}
+        out["phases_ms"] = {"eig_ms": eig_ms, "total_ms_instrumented": acc["total_ms"] / reps}
+    if rank == 0 and world == 1 and not args.no_per_layer:
+        seen, per_layer = {}, []
+        for i, L in enumerate(layers):
+            sig = (tuple(L["W"].shape), tuple(L["ranks"]))
+            if sig in seen:
+                seen[sig]["count"] += 1
+                continue
+            one = dict(W=L["W"], U=torch.zeros_like(L["W"]), Z=torch.empty_like(L["W"]), ranks=L["ranks"])
+            pl = ops.TuckerPlan([one])
+            for _ in range(2):
+                pl.run(update_u=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                pl.run(update_u=True)
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / 5
+            it1, _ = pl.iterations()
+            pl.close()
+            f = tucker_flops(L["W"].shape, L["ranks"], it1[0])
+            svd = 0.0          # thin-SVD model 4MN^2 + 8N^3 of every unfolding the run decomposed
+            O, I = L["W"].shape[0], L["W"].shape[1]
+            k2 = L["W"][0, 0].numel()
+            ro, ri = L["ranks"]
+            svd += sched.svd_flops(O, I * k2) + sched.svd_flops(I, O * k2)
+            svd += it1[0] * (sched.svd_flops(O, k2 * min(ri, I)) + sched.svd_flops(I, k2 * min(ro, O)))
+            rec = {"layer": names[i], "shape": list(L["W"].shape), "ranks": list(L["ranks"]), "count": 1, "hooi_sweeps": it1[0],
+                   "svd_gflop": svd / 1e9, "ms_alone": ms, "svd_gflops_per_s": svd / (ms * 1e-3) / 1e9}
+            seen[sig] = rec
+            per_layer.append(rec)
+        out["per_layer_svd_gflops"] = per_layer
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.config)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if args.config.endswith("_tk"):
+        return bench_tucker(args)
 
     import numpy as np
     import torch
@@ -283,25 +492,18 @@ def main():
         my_gram = sum(flops[i]["gram"] for i in mine)
         my_mfma32 = sum(flops[i]["proj"] + flops[i]["rec"] for i in mine)
         my_bytes = 16.0 * sum(flops[i]["numel"] for i in mine)
-        pm = {}
-        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH_SIZE
-               # doubled as MI355X_MICROARCH.md prescribes); bench.py cannot run rocprofv3 itself
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
-        except Exception:
-            pass
+        pm, pm_meta = load_pmc_traffic(args.config)
         total_ms = sum(v for k, v in ph.items() if k.endswith("_ms"))
         roof_tick = None
         if jt["tick_launches"] > 0 and jt["tick_ms"] > 0:
             tick_tf = jt["tick_flops"] / (jt["tick_ms"] * 1e-3) / 1e12
-            ttraffic = pm.get("jacobi_tick3_kernel", {}).get("hbm_bytes_per_launch_corrected") \
-                if args.config == "resnet50_tt" and world == 1 else None
+            ttraffic, tsrc = pmc_traffic_for(pm, pm_meta, "jacobi_tick3_kernel", jt["tick_launches"] / reps, world)
             roof_tick = {
                 "bound": "mfma", "kernel": "jacobi_tick3_kernel (block-Jacobi tournament of the Rayleigh-Ritz and full eigen-solves: "
                                            "fp64 MFMA Gram / column updates around two serial 16x16 rotation solves)",
                 "achieved": tick_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tick_tf / PEAK_F64_MFMA_TFLOPS,
                 "peak_measured": PEAK_F64_MFMA_MEASURED_TFLOPS, "frac_of_measured": tick_tf / PEAK_F64_MFMA_MEASURED_TFLOPS,
-                "traffic": ttraffic,
-                "traffic_source": "profiles/r02_pmc_traffic.json (per launch)" if ttraffic else None,
+                "traffic": ttraffic, "traffic_source": tsrc,
                 "launches_per_step": jt["tick_launches"] / reps,
                 "avg_launch_us": 1e3 * jt["tick_ms"] / jt["tick_launches"],
                 "workgroups_per_launch": jt["tick_wgs"] / jt["tick_launches"],
@@ -316,15 +518,13 @@ def main():
         roof_gemm = None
         if ft["gemm_launches"] > 0 and ft["gemm_ms"] > 0:
             gemm_tf = ft["gemm_flops"] / (ft["gemm_ms"] * 1e-3) / 1e12
-            traffic = pm.get("dgemm_nt_tile_kernel", {}).get("hbm_bytes_per_launch_corrected") \
-                if args.config == "resnet50_tt" and world == 1 else None
+            traffic, gsrc = pmc_traffic_for(pm, pm_meta, "dgemm_nt_tile_kernel", ft["gemm_launches"] / reps, world)
             roof_gemm = {
                 "bound": "mfma", "kernel": "dgemm_nt_tile_kernel<32,2> (fp64 MFMA 16x16x4, 64x32 tiles, eight waves: block products of the "
                                            "filtered eigen-solver)",
                 "achieved": gemm_tf, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F64_MFMA_TFLOPS,
                 "peak_measured": PEAK_F64_MFMA_MEASURED_TFLOPS, "frac_of_measured": gemm_tf / PEAK_F64_MFMA_MEASURED_TFLOPS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r02_pmc_traffic.json (per launch)" if traffic else None,
+                "traffic": traffic, "traffic_source": gsrc,
                 "launches_per_step": ft["gemm_launches"] / reps,
                 "avg_launch_us": 1e3 * ft["gemm_ms"] / ft["gemm_launches"],
                 "time_share": (ft["gemm_ms"] / reps) / max(1e-9, total_ms),

@@ -242,26 +242,41 @@ __global__ __launch_bounds__(1024) void filt_guard_kernel(const FiltProb* __rest
     for (int k = 0; k < 16; ++k) t += red[k];
     return t;
   };
-  auto project = [&](double* v) {                        // v <- (I - Q Q^T) v
-    for (int j = wave; j < rp; j += 16) {
-      const double* row = Q + (int64_t)j * ldy;
-      double a = 0.0;
-      for (int i = lane; i < N; i += 64) a += row[i] * v[i];
-      a = wave_sum(a);
-      if (lane == 0) c[j] = a;
+  // y[j] = <rows[j], x> for j < nrows (rows contiguous, leading dimension ld): a wave takes four rows at a time so that
+  // 4 x N/64 loads are in flight per lane -- the phase is bound by load latency, not by bytes
+  auto rows_dot = [&](const double* __restrict__ rows, int ld, int nrows, const double* x, double* y) {
+    for (int j0 = wave * 4; j0 < nrows; j0 += 64) {
+      const double* r0 = rows + (int64_t)j0 * ld;
+      const bool h1 = j0 + 1 < nrows, h2 = j0 + 2 < nrows, h3 = j0 + 3 < nrows;
+      const double* r1 = h1 ? r0 + ld : r0;
+      const double* r2 = h2 ? r0 + 2 * (int64_t)ld : r0;
+      const double* r3 = h3 ? r0 + 3 * (int64_t)ld : r0;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (int i = lane; i < N; i += 64) {
+        const double xv = x[i];
+        a0 += r0[i] * xv; a1 += r1[i] * xv; a2 += r2[i] * xv; a3 += r3[i] * xv;
+      }
+      a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+      if (lane == 0) {
+        y[j0] = a0;
+        if (h1) y[j0 + 1] = a1;
+        if (h2) y[j0 + 2] = a2;
+        if (h3) y[j0 + 3] = a3;
+      }
     }
+  };
+  auto project = [&](double* v) {                        // v <- (I - Q Q^T) v
+    rows_dot(Q, ldy, rp, v, c);
     __syncthreads();
     for (int i = tid; i < N; i += 1024) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int j = 0;
-      for (; j + 3 < rp; j += 4) {
-        a0 += c[j] * Q[(int64_t)j * ldy + i];
-        a1 += c[j + 1] * Q[(int64_t)(j + 1) * ldy + i];
-        a2 += c[j + 2] * Q[(int64_t)(j + 2) * ldy + i];
-        a3 += c[j + 3] * Q[(int64_t)(j + 3) * ldy + i];
+      for (; j + 7 < rp; j += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += c[j + u] * Q[(int64_t)(j + u) * ldy + i];
       }
-      for (; j < rp; ++j) a0 += c[j] * Q[(int64_t)j * ldy + i];
-      v[i] -= (a0 + a1) + (a2 + a3);
+      for (; j < rp; ++j) a[0] += c[j] * Q[(int64_t)j * ldy + i];
+      v[i] -= ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     __syncthreads();
   };
@@ -279,13 +294,7 @@ __global__ __launch_bounds__(1024) void filt_guard_kernel(const FiltProb* __rest
     __syncthreads();
   }
   for (int s = 0; s < nsteps; ++s) {
-    for (int i = wave; i < N; i += 16) {                 // w = G z  (G symmetric: row i is contiguous)
-      const double* row = G + (int64_t)i * ldg;
-      double a = 0.0;
-      for (int k = lane; k < N; k += 64) a += row[k] * z[k];
-      a = wave_sum(a);
-      if (lane == 0) w[i] = a;
-    }
+    rows_dot(G, ldg, N, z, w);                           // w = G z  (G symmetric: row i is contiguous)
     __syncthreads();
     project(w);
     double a = 0.0, b = 0.0;

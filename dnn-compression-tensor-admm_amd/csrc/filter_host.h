@@ -2,6 +2,7 @@
 // sequence of one group of problems.  Used by the TT plan (plan.hip) for the eigen-problems whose kept rank is a
 // fraction of their size, and by tadmm_eigh_top_f64 (tests).
 #pragma once
+#include <memory>
 #include "host.h"
 
 namespace tadmm {
@@ -49,8 +50,32 @@ struct FilterTiming {
   double fast_ms = 0.0; int fast_launches = 0; double fast_flops = 0.0;      // dgemm3 launches (algorithmic flops)
 };
 
+// Side stream of the guard (filt_guard_kernel): it only needs the final orthonormal block, so it runs BESIDE the
+// Rayleigh-Ritz solve (a chain of latency-bound launches on a handful of CUs) instead of in front of the verdict.
+struct GuardSide {
+  hipStream_t st = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+  GuardSide() {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) == hipSuccess &&
+         hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+  }
+  ~GuardSide() {
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  GuardSide(const GuardSide&) = delete;
+  GuardSide& operator=(const GuardSide&) = delete;
+};
+
 struct FilterGroup {
   int nf = 0;
+  std::shared_ptr<GuardSide> side;           // created at the first run (on the plan's device)
+  bool guard_forked = false;
   int npad_max = 0, rp_max = 0;              // LDS of the guard kernel
   int max_degree = 8;
   size_t prob_off = 0;                       // FiltProb[nf]
@@ -408,6 +433,15 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   fg.fast_stages = std::max(0, stages - 1);              // next run: every stage but the last one this run needed
   cholqr(fg.gramB, fg.cholB_off);        // second pass: orthonormal to rounding
   launch_filt_flags(probs, fg.nf, s);
+  fg.guard_forked = false;
+  if (filter_guard_steps() > 0) {            // the guard reads the final block Q = ring[base] and G only: fork it here
+    if (!fg.side) fg.side = std::make_shared<GuardSide>();
+    if (fg.side->ok && hipEventRecord(fg.side->fork, s) == hipSuccess &&
+        hipStreamWaitEvent(fg.side->st, fg.side->fork, 0) == hipSuccess) {
+      launch_filt_guard(probs, fg.nf, fg.npad_max, fg.rp_max, filter_guard_steps(), fg.side->st);
+      fg.guard_forked = hipEventRecord(fg.side->join, fg.side->st) == hipSuccess;
+    }
+  }
   gemm(fg.tfinal);
   gemm(fg.hform);
   if (debug) fprintf(stderr, "[tadmm] filter: %d problems, %d stages of <= %d steps\n", fg.nf, stages, fg.max_degree);
@@ -424,7 +458,8 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
   const FiltProb* probs = (const FiltProb*)D(fg.prob_off);
   const FiltParams prm = filter_params(fg);
   launch_filt_theta(probs, fg.nf, s);
-  launch_filt_guard(probs, fg.nf, fg.npad_max, fg.rp_max, filter_guard_steps(), s);
+  if (fg.guard_forked) HIP_OK(h, hipStreamWaitEvent(s, fg.side->join, 0));
+  else launch_filt_guard(probs, fg.nf, fg.npad_max, fg.rp_max, filter_guard_steps(), s);     // (no side stream: in line)
   launch_dgemm((const DgemmDesc*)D(fg.uform.desc_off), (const BlockRef*)D(fg.uform.map_off), fg.uform.nblocks, false, s);
   {
     const bool t = tm && tm->on;

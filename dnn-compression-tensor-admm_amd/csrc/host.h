@@ -216,6 +216,8 @@ struct JacobiTiming {
   bool on = false;
   hipEvent_t a{}, b{};
   double tick_ms = 0.0; int tick_launches = 0; double tick_flops = 0.0; double tick_wgs = 0.0;
+  double small_ms = 0.0; int small_launches = 0; double small_flops = 0.0;    // single-launch solver (<= 64 columns)
+  const int* small_n = nullptr;       // per problem: N of its eigen-problem (8 N^3 model of the launch's work)
 };
 
 // One grouped eigen-solve: `neig` symmetric problems whose descriptors / block maps already sit on the device.
@@ -260,7 +262,17 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
   {
     const char* e = getenv("TADMM_JACOBI_SMALL");     // 0: always use the tick kernels (A/B measurements)
     if (g.npad_max > 0 && jacobi_small_fits(g.npad_max) && !(e && !atoi(e))) {
+      const bool timed = jt && jt->on;
+      if (timed) (void)hipEventRecord(jt->a, s);
       launch_jacobi_small(g.ed, g.neig, g.npad_max, tol, std::max(max_sweeps, 60), g.skip, poll.host, s, g.warm);
+      if (timed) {
+        float ms = 0.f;
+        (void)hipEventRecord(jt->b, s);
+        (void)hipEventSynchronize(jt->b);
+        (void)hipEventElapsedTime(&ms, jt->a, jt->b);
+        jt->small_ms += ms; jt->small_launches += 1;
+        for (int q = 0; q < g.neig && jt->small_n; ++q) { const double nn = jt->small_n[q]; jt->small_flops += 8.0 * nn * nn * nn; }
+      }
       HIP_OK(h, hipEventRecord(poll.ev[0], s));
       *small_pending = true;
       return TADMM_OK;

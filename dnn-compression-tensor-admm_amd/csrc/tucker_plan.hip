@@ -81,6 +81,7 @@ struct Lsv {     // one grouped "leading singular vectors" phase over all layers
   Group gram_p, gram_r, tick, self, norm, ext, xg;
   size_t eig_desc_off = 0;
   std::vector<int> players;
+  std::vector<int> players_n;     // per problem: N of the eigen-problem (timing: 8 N^3 model)
   int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0;
   bool warm = false;              // some problem of the group has a warm-start image
   size_t tick_lds = 0;
@@ -211,6 +212,11 @@ struct tadmm_tucker_plan_s {
   int inner = 1, max_sweeps = 40, n_iter_max = 100;
   bool debug = false;
   int last_hooi = 0, last_jacobi_sweeps = 0;
+  // instrumented runs (tadmm_tucker_enable_timing): every launch of the eigen-solver timed on the launch stream
+  JacobiTiming jtm;
+  bool ev_made = false;
+  hipEvent_t tev[4];
+  double last_total_ms = 0.0;
 };
 
 // Lays the plan out in `base` (nullptr: sizes only).  `img` receives the host copy of the descriptor region.
@@ -361,6 +367,7 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
     std::vector<BlockRef> m_gp, m_gr, m_tick, m_self, m_norm, m_ext, m_xg;
     std::vector<int> gp_cost(n);
     v.players.assign(n, 0);
+    v.players_n.assign(n, 0);
     v.ld_max = 0;
     v.npad_max = 0;
     v.warm = false;
@@ -431,6 +438,7 @@ static int tucker_layout(tadmm_tucker_plan_s* P, char* base, const float* const*
       else { e.mode = 3; e.out_a = (float*)dev(t.Vs); e.ldo = 0; }
       const int units = v.mode >= 1 ? g.nb / 2 : g.nb;
       v.players[l] = units;
+      v.players_n[l] = g.N;
       v.gsteps = std::max(v.gsteps, units - 1);
       for (int b = 0; b < units / 2; ++b) m_tick.push_back(BlockRef{l, b});
       if (v.mode >= 2) for (int b = 0; b < units; ++b) m_self.push_back(BlockRef{l, b});
@@ -621,7 +629,8 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
       };
     int gs = 0;
     bool small_pending = false;
-    const int rc = run_eig_group(h, eg, p->poll, p->jtol, p->inner, p->max_sweeps, p->debug, s, &gs, &small_pending);
+    p->jtm.small_n = v.players_n.empty() ? nullptr : v.players_n.data();
+    const int rc = run_eig_group(h, eg, p->poll, p->jtol, p->inner, p->max_sweeps, p->debug, s, &gs, &small_pending, &p->jtm);
     if (rc != TADMM_OK) return rc;
     jac_sweeps += gs;
     launch_eig_norms(ed, (const BlockRef*)D(v.norm.map_off), v.norm.nblocks, s, sk);
@@ -639,6 +648,9 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
     launch_gemm((const GemmDesc*)D(p->gemm[k].desc_off), (const BlockRef*)D(p->gemm[k].map_off), p->gemm[k].nblocks, s, sk);
   };
 
+  p->jtm.tick_ms = p->jtm.small_ms = 0.0; p->jtm.tick_launches = p->jtm.small_launches = 0;
+  p->jtm.tick_flops = p->jtm.small_flops = p->jtm.tick_wgs = 0.0;
+  if (p->jtm.on) (void)hipEventRecord(p->tev[2], s);
   HIP_OK(h, hipMemsetAsync(skip, 0, (size_t)n * 4, s));
   HIP_OK(h, hipMemsetAsync(D(p->warm_ok_off), 0, (size_t)n * 2 * 4, s));     // a new tensor: every HOOI solve starts cold once
   HIP_OK(h, hipMemsetAsync(D(p->err_off), 0, (size_t)n * 16, s));
@@ -705,6 +717,13 @@ int tadmm_tucker_run(tadmm_tucker_plan p, int update_u, int use_u, double* resid
                      update_u, partial, s);
   if (resid_sq_dev) launch_resid_reduce((const SweepDesc*)D(p->sweep_desc_off), n, partial, resid_sq_dev, s);
   HIP_OK(h, hipGetLastError());
+  if (p->jtm.on) {
+    float ms = 0.f;
+    (void)hipEventRecord(p->tev[3], s);
+    (void)hipEventSynchronize(p->tev[3]);
+    (void)hipEventElapsedTime(&ms, p->tev[2], p->tev[3]);
+    p->last_total_ms = ms;
+  }
   if (p->debug) fprintf(stderr, "[tadmm] tucker: %d layers, HOOI sweeps (max over layers) %d, Jacobi sweeps %d\n", n,
                         p->last_hooi, jac_sweeps);
   return TADMM_OK;
@@ -720,6 +739,28 @@ int tadmm_tucker_factors(tadmm_tucker_plan p, int layer, const float** core, con
 }
 
 int tadmm_tucker_jacobi_sweeps(tadmm_tucker_plan p) { return p ? p->last_jacobi_sweeps : TADMM_ERR_INVALID; }
+
+int tadmm_tucker_enable_timing(tadmm_tucker_plan p, int on) {
+  DeviceGuard device_guard(p ? p->h : nullptr);
+  if (!p) return TADMM_ERR_INVALID;
+  if (on && !p->ev_made) {
+    for (auto& e : p->tev) if (hipEventCreate(&e) != hipSuccess) return TADMM_ERR_HIP;
+    p->ev_made = true;
+    p->jtm.a = p->tev[0]; p->jtm.b = p->tev[1];
+  }
+  p->jtm.on = on != 0;
+  return TADMM_OK;
+}
+
+// out[0] = summed ms of the eigen-solver launches of the last run, [1] = their number, [2] = 8 N^3 model flops they stand
+// for, [3] = ms of the whole run, [4] = HOOI sweeps (max over layers), [5..7] reserved
+int tadmm_tucker_last_timing(tadmm_tucker_plan p, double out[8]) {
+  if (!p || !out) return TADMM_ERR_INVALID;
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  out[0] = p->jtm.small_ms + p->jtm.tick_ms; out[1] = p->jtm.small_launches + p->jtm.tick_launches;
+  out[2] = p->jtm.small_flops; out[3] = p->last_total_ms; out[4] = p->last_hooi;
+  return TADMM_OK;
+}
 
 int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double* errors_out_host, void* stream_) {
   DeviceGuard device_guard(p ? p->h : nullptr);
@@ -744,6 +785,7 @@ int tadmm_tucker_destroy(tadmm_tucker_plan p) {
   if (!p) return TADMM_OK;
   p->poll.destroy();
   p->hooi.destroy();
+  if (p->ev_made) for (auto& e : p->tev) (void)hipEventDestroy(e);
   delete p;
   return TADMM_OK;
 }

@@ -113,6 +113,8 @@ ABI = {
     "tadmm_tucker_factors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p)]),
     "tadmm_tucker_jacobi_sweeps": (C.c_int, [C.c_void_p]),
+    "tadmm_tucker_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "tadmm_tucker_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "tadmm_tucker_iterations": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p]),
     "tadmm_tucker_destroy": (C.c_int, [C.c_void_p]),
     "tadmm_penalty_scratch_doubles": (C.c_int, []),

@@ -262,6 +262,15 @@ class TuckerPlan:
         """Jacobi sweeps summed over all eigen-solve groups of the last run."""
         return int(self.h.lib.tadmm_tucker_jacobi_sweeps(self._plan))
 
+    def enable_timing(self, on: bool = True):
+        self.h.check(self.h.lib.tadmm_tucker_enable_timing(self._plan, int(on)))
+
+    def last_timing(self) -> dict:
+        """Instrumented run: eigen-solver launches timed one by one with HIP events on the launch stream."""
+        out = (C.c_double * 8)()
+        self.h.check(self.h.lib.tadmm_tucker_last_timing(self._plan, out))
+        return dict(eig_ms=out[0], eig_launches=int(out[1]), eig_model_flops=out[2], total_ms=out[3], hooi_sweeps=int(out[4]))
+
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan:
             self.h.lib.tadmm_tucker_destroy(self._plan)

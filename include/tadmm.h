@@ -173,6 +173,11 @@ int tadmm_tucker_iterations(tadmm_tucker_plan p, int32_t* iters_out_host, double
 /* Jacobi sweeps summed over every eigen-solve group of the last run (HOSVD start + two per HOOI sweep): the figure the
  * warm start of the HOOI solves lowers; host-side counter, no synchronisation.  Negative on a null plan. */
 int tadmm_tucker_jacobi_sweeps(tadmm_tucker_plan p);
+/* Instrumented runs (bench.py): every launch of the eigen-solver is bracketed by HIP events on the launch stream (adds a
+ * stream sync per launch).  last_timing: out[0] = summed ms of those launches in the last run, [1] = their number,
+ * [2] = the 8 N^3 model FLOPs they stand for, [3] = ms of the whole run, [4] = HOOI sweeps (max over layers). */
+int tadmm_tucker_enable_timing(tadmm_tucker_plan p, int on);
+int tadmm_tucker_last_timing(tadmm_tucker_plan p, double out[8]);
 int tadmm_tucker_destroy(tadmm_tucker_plan p);
 
 /* ---- augmented-Lagrangian penalty (admm.py:80-85) ---------------------- */

@@ -90,7 +90,19 @@ if ff and fw:
             per[name]["launches"] = n
     for name, d in per.items():
         d["hbm_bytes_per_launch_corrected"] = (2 * d.get("FETCH_SIZE_KiB_per_launch_raw", 0.0) + d.get("WRITE_SIZE_KiB_per_launch_raw", 0.0)) * 1024
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --no-per-layer, ResNet-50 TT",
+    # provenance: bench.py only stamps `traffic` onto a run whose launch count per step matches this pass
+    commit = sys.argv[2] if len(sys.argv) > 2 else os.environ.get("TADMM_COMMIT", "unknown")
+    config = sys.argv[3] if len(sys.argv) > 3 else "resnet50_tt"
+    lanes = 1
+    try:
+        lanes = int(json.loads(open(os.path.join(out, "pmc_fetch_bench.json")).read().strip().splitlines()[-1])["lanes"]["n"])
+    except Exception:
+        pass
+    runs = max(1, per.get("unfold_kernel", {}).get("launches", lanes) // max(1, lanes))      # plan runs in the pass
+    for name, d in per.items():
+        d["launches_per_step"] = d["launches"] / runs
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 2 --warmup 1 --no-per-layer, " + config,
+               "commit": commit, "config": config, "plan_runs_in_pass": runs, "lanes": lanes,
                "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (FETCH_SIZE counts 64 B per 128-B request on gfx950)",
                "kernels": {k: v for k, v in per.items() if not k.startswith("at::") and not k.startswith("__amd")}},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)

@@ -279,7 +279,10 @@ def test_admm_update_every_distinct_resnet50_shape_vs_oracle(dev):
         err = np.linalg.norm((got - z).astype(np.float64)) / np.linalg.norm(z.astype(np.float64))
         assert err <= REL, (name, err)
         np.testing.assert_allclose(a.u[name].cpu().numpy(), w - got, atol=1e-6)
-        assert abs(a.logger[name][0] - np.linalg.norm((w - z).astype(np.float64))) <= 1e-4 * a.logger[name][0] + 1e-6
+        # (a full-rank layer projects onto itself: both residuals are fp32 rounding noise of order eps * ||w||, and the
+        # device's got SMALLER with the compensated GEMM accumulation of round 3 -- hence the eps-scaled absolute term)
+        noise = 4 * np.finfo(np.float32).eps * np.linalg.norm(w.astype(np.float64))
+        assert abs(a.logger[name][0] - np.linalg.norm((w - z).astype(np.float64))) <= 1e-4 * a.logger[name][0] + noise
     assert len(seen) == 12
 
 
