@@ -118,8 +118,15 @@ void launch_jacobi_self(const EigDesc* descs_dev, const BlockRef* map_dev, int n
 // verdict_pinned[1 + p]
 bool jacobi_small_fits(int npad_max);
 // warm: reserve the second LDS image a warm-started problem needs (EigDesc::warm)
+// `fast_done` (optional): per-problem words set by eig_small_direct_kernel -- those problems are finished already
 void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, double tol, int max_sweeps,
-                         const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm = false);
+                         const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm,
+                         const int32_t* fast_done = nullptr);
+// tridiag.hip: direct solver (tridiagonalisation + bisection + inverse iteration) for problems of at most 64 columns;
+// verified results only, everything else is left to jacobi_small_kernel
+bool eig_small_direct_on();
+void launch_eig_small_direct(const EigDesc* descs_dev, int nprob, const int32_t* skip, int32_t* fast_done_dev,
+                             int* verdict_pinned, hipStream_t s);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,
                       const int32_t* skip = nullptr);
 // npad_max: largest padded problem size of the launch (sizes the eigenvalue table in LDS; 0 = the largest supported)

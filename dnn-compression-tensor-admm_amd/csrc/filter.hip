@@ -226,6 +226,7 @@ __global__ __launch_bounds__(1024) void filt_guard_kernel(const FiltProb* __rest
   double* z = gsm;
   double* w = z + Npad;
   double* c = w + Npad;
+  double* pacc = c + rp;                                 // [nparts][Npad] partial sums of the projection
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto wave_sum = [&](double v) {
 #pragma unroll
@@ -265,18 +266,43 @@ __global__ __launch_bounds__(1024) void filt_guard_kernel(const FiltProb* __rest
       }
     }
   };
-  auto project = [&](double* v) {                        // v <- (I - Q Q^T) v
+  // v <- (I - Q Q^T) v.  The update v[i] -= sum_j c_j Q[j][i] is a chain of rp loads per element: the j range is split over
+  // `nparts` thread groups (all 1024 threads busy at N <= 512) with 8 loads in flight each; partial sums meet in LDS.
+  const int Nc = (N + 63) & ~63;
+  const int nparts = max(1, 1024 / Nc);
+  auto project = [&](double* v) {
     rows_dot(Q, ldy, rp, v, c);
     __syncthreads();
-    for (int i = tid; i < N; i += 1024) {
-      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int j = 0;
-      for (; j + 7 < rp; j += 8) {
+    const int part = tid / Nc, i = tid - part * Nc;
+    if (nparts > 1) {
+      if (part < nparts && i < N) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int per = (rp / nparts + 7) & ~7, j0 = part * per, j1 = min(rp, j0 + per);
+        int j = j0;
+        for (; j + 7 < j1; j += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += c[j + u] * Q[(int64_t)(j + u) * ldy + i];
+          for (int u = 0; u < 8; ++u) a[u] += c[j + u] * Q[(int64_t)(j + u) * ldy + i];
+        }
+        for (; j < j1; ++j) a[0] += c[j] * Q[(int64_t)j * ldy + i];
+        pacc[part * Npad + i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
       }
-      for (; j < rp; ++j) a[0] += c[j] * Q[(int64_t)j * ldy + i];
-      v[i] -= ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      __syncthreads();
+      for (int k = tid; k < N; k += 1024) {
+        double t = 0.0;
+        for (int q = 0; q < nparts; ++q) t += pacc[q * Npad + k];
+        v[k] -= t;
+      }
+    } else {
+      for (int k = tid; k < N; k += 1024) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int j = 0;
+        for (; j + 7 < rp; j += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] += c[j + u] * Q[(int64_t)(j + u) * ldy + k];
+        }
+        for (; j < rp; ++j) a[0] += c[j] * Q[(int64_t)j * ldy + k];
+        v[k] -= ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
     }
     __syncthreads();
   };
@@ -361,7 +387,7 @@ void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nb
 }
 void launch_filt_guard(const FiltProb* probs_dev, int nprob, int npad_max, int rp_max, int steps, hipStream_t s) {
   if (nprob <= 0 || steps <= 0) return;
-  const size_t lds = ((size_t)2 * npad_max + rp_max) * sizeof(double);
+  const size_t lds = ((size_t)2 * npad_max + rp_max + (size_t)std::max(1, 1024 / std::max(64, npad_max)) * 1024 + 1024) * sizeof(double);
   hipLaunchKernelGGL(filt_guard_kernel, dim3(nprob), dim3(1024), lds, s, probs_dev, steps);
 }
 void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int stage_fast, int* verdict_pinned,

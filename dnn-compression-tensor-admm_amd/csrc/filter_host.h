@@ -24,7 +24,7 @@ static inline int filter_block_size(int N, int r) {
 // power steps of the independent guard (filt_guard_kernel); TADMM_FILTER_GUARD=0 switches it off (A/B, tests)
 static inline int filter_guard_steps() {
   if (const char* e = getenv("TADMM_FILTER_GUARD")) return std::max(0, std::min(16, atoi(e)));
-  return 4;
+  return 3;
 }
 
 static inline int filter_tile_n() {

@@ -78,27 +78,24 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
   const int K = d.K;
   // Accumulation.  One fp32 MFMA accumulator over all of K rounds K times; when every product is equal (constant or
   // rank-1 weights: all partial sums round the same way) the error grows like K eps instead of sqrt(K) eps and reached
-  // 1.3e-5 of ||W|| at K = 4608 -- above the 1e-5 parity bar.  The K range is therefore accumulated in chunks of BK = 16
-  // (8 MFMAs) into two alternating accumulators, and each finished chunk is folded into a compensated (Kahan) total
-  // on the vector ALU while the matrix pipe works on the other accumulator: error <= 16 eps inside a chunk + ~2 eps for
-  // the sum of the chunks, whatever K.
+  // 1.3e-5 of ||W|| at K = 4608 -- above the 1e-5 parity bar.  The K range is therefore accumulated in chunks of 2 BK = 32
+  // (16 MFMAs) into two alternating accumulators, and each finished chunk is added to an fp64 total on the vector ALU
+  // (a convert and an add per entry) while the matrix pipe works on the other accumulator: error <= 32 eps inside a
+  // chunk (~1e-6 relative in the all-equal worst case), nothing from the sum of the chunks, whatever K.
+  typedef double double16_t __attribute__((ext_vector_type(16)));
   const float16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float16_t acc0 = zero16, acc1 = zero16, tot = zero16, cmp = zero16;
+  float16_t acc0 = zero16, acc1 = zero16;
+  double16_t tot = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto fold = [&](float16_t& a) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float y = a[e] - cmp[e];
-      const float t = tot[e] + y;
-      cmp[e] = (t - tot[e]) - y;
-      tot[e] = t;
-    }
+    for (int e = 0; e < 16; ++e) tot[e] += (double)a[e];
     a = zero16;
   };
 
   Frag4 fa = load_tile4(d.A, d.a_rs, d.a_cs, a_k, m0, d.M, 0, K, tid);
   Frag4 fb = load_tile4(d.B, d.b_cs, d.b_rs, b_k, n0, d.N, 0, K, tid);
   const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kq = lane >> 5;
-  auto chunk = [&](int k0, float16_t& acc, float16_t& other) {
+  auto step = [&](int k0, float16_t& acc) {
     store_tile4(As, LDA, a_k, fa, tid);
     store_tile4(Bs, LDB, b_k, fb, tid);
     __syncthreads();
@@ -112,16 +109,24 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
       const float b = Bs[(kk + kq) * LDB + bj];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    fold(other);                      // the previous chunk (its MFMAs retired an iteration ago): overlaps with this chunk's
-    __syncthreads();
   };
-  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
-    chunk(k0, acc0, acc1);
-    if (k0 + BK < K) chunk(k0 + BK, acc1, acc0);
+  for (int k0 = 0; k0 < K; k0 += 4 * BK) {
+    step(k0, acc0);
+    fold(acc1);                        // the previous chunk (its MFMAs retired long ago): overlaps with this chunk's
+    __syncthreads();
+    if (k0 + BK < K) { step(k0 + BK, acc0); __syncthreads(); }
+    if (k0 + 2 * BK < K) {
+      step(k0 + 2 * BK, acc1);
+      fold(acc0);
+      __syncthreads();
+      if (k0 + 3 * BK < K) { step(k0 + 3 * BK, acc1); __syncthreads(); }
+    }
   }
   fold(acc0);
   fold(acc1);
-  const float16_t acc = tot;
+  float16_t acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = (float)tot[e];
 
   // epilogue: D row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
   const int col = n0 + wn * 32 + (lane & 31);

@@ -264,7 +264,11 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
     if (g.npad_max > 0 && jacobi_small_fits(g.npad_max) && !(e && !atoi(e))) {
       const bool timed = jt && jt->on;
       if (timed) (void)hipEventRecord(jt->a, s);
-      launch_jacobi_small(g.ed, g.neig, g.npad_max, tol, std::max(max_sweeps, 60), g.skip, poll.host, s, g.warm);
+      // direct route first (tridiag.hip); the Jacobi launch behind it skips what that one solved and verified.  The flag
+      // words live in the group's `prev` scratch (doubles of the tick path's convergence kernel, unused here).
+      int32_t* fast = (g.prev_dev && eig_small_direct_on()) ? reinterpret_cast<int32_t*>(g.prev_dev) : nullptr;
+      if (fast) launch_eig_small_direct(g.ed, g.neig, g.skip, fast, poll.host, s);
+      launch_jacobi_small(g.ed, g.neig, g.npad_max, tol, std::max(max_sweeps, 60), g.skip, poll.host, s, g.warm, fast);
       if (timed) {
         float ms = 0.f;
         (void)hipEventRecord(jt->b, s);

@@ -1009,9 +1009,11 @@ constexpr int kSmallWaveScratch = 2 * kPair * kHP;     // H and Q of one wave
 
 __global__ __launch_bounds__(256) void jacobi_small_kernel(const EigDesc* __restrict__ descs,
                                                            const int32_t* __restrict__ skip, double tol,
-                                                           int max_sweeps, int* __restrict__ verdict) {
+                                                           int max_sweeps, int* __restrict__ verdict,
+                                                           const int32_t* __restrict__ fast_done) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int p = blockIdx.x;
+  if (fast_done && fast_done[p]) return;     // solved (and verified) by eig_small_direct_kernel (tridiag.hip)
   const EigDesc d = descs[p];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (skip && skip[p]) {
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(256) void jacobi_small_kernel(const EigDesc* __rest
 bool jacobi_small_fits(int npad_max) { return npad_max <= kSmallNpad; }
 
 void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, double tol, int max_sweeps,
-                         const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm) {
+                         const int32_t* skip, int* verdict_pinned, hipStream_t s, bool warm, const int32_t* fast_done) {
   if (nprob <= 0) return;
   // X image | 4 wave scratches | red[8] + flags (8 doubles) | second image (warm start only)
   const size_t lds = ((size_t)npad_max * (npad_max + 2) * (warm ? 2 : 1) + 4 * kSmallWaveScratch + 16) * 8;
@@ -1172,7 +1174,7 @@ void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, doub
     }
   }
   hipLaunchKernelGGL(jacobi_small_kernel, dim3(nprob), dim3(256), lds, s, descs_dev, skip, tol, max_sweeps,
-                     verdict_pinned);
+                     verdict_pinned, fast_done);
 }
 
 #ifdef TADMM_STAMPS

@@ -1522,10 +1522,27 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   for (int b = 0; b < nb / 2; ++b) vs2.push_back(BlockRef{0, b});
   HIP_OK(h, hipMemcpyAsync(m_self, vs2.data(), vs2.size() * sizeof(BlockRef), hipMemcpyHostToDevice, s));
   HIP_OK(h, hipStreamSynchronize(s));
-  launch_jacobi_init(edev, 1, s);
   const double tol = 1e-9;
   int tick = 0, gs = 0;
   bool conv = false;
+  // problems of at most 64 columns take the route the plans take (run_eig_group): the direct solver of tridiag.hip, then
+  // jacobi_small_kernel for whatever that one did not certify.  TADMM_EIGH_TICK=1 keeps them on the tournament kernels.
+  if (jacobi_small_fits(Npad) && !(getenv("TADMM_EIGH_TICK") && atoi(getenv("TADMM_EIGH_TICK")))) {
+    int32_t* fast = done + 4;                 // device words inside the 64-byte `done` slot: [4] direct-solver flag,
+    int* verdict = (int*)(done + 8);          // [8..9] verdict of the single-launch solvers
+    HIP_OK(h, hipMemsetAsync(done, 0, 64, s));
+    const bool direct = eig_small_direct_on();
+    if (direct) launch_eig_small_direct(edev, 1, nullptr, fast, verdict, s);
+    launch_jacobi_small(edev, 1, Npad, tol, 60, nullptr, verdict, s, false, direct ? fast : nullptr);
+    int hv[6] = {0, 0, 0, 0, 0, 0};
+    HIP_OK(h, hipMemcpyAsync(hv, done + 4, sizeof hv, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipStreamSynchronize(s));
+    conv = hv[5] != 0;                        // verdict[1]
+    gs = hv[0] ? 0 : 1;                       // 0 sweeps: solved by the direct route
+    if (sweeps_out) *sweeps_out = gs;
+    if (!conv) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "small eigen-solve did not converge");
+  } else {
+  launch_jacobi_init(edev, 1, s);
   double hoff[3];
   int hdone = 0;
   for (; gs < 40 && !conv; ++gs) {
@@ -1545,6 +1562,7 @@ int tadmm_eigh_f64(tadmm_handle h, const double* G, int N, double* evals_out, do
   if (sweeps_out) *sweeps_out = gs;
   if (getenv("TADMM_STAMPS_DUMP")) { (void)hipStreamSynchronize(s); dump_stamps(); }   // -DTADMM_STAMPS builds only
   if (!conv) CTX_FAIL(h, TADMM_ERR_NOCONVERGE, "Jacobi did not converge in 40 sweeps");
+  }
   launch_eig_norms(edev, m_norm, (int)vn.size(), s);
   launch_eig_sort(edev, 1, s, nullptr, Npad);
   launch_eig_extract(edev, m_ext, (int)ve.size(), s);

@@ -157,7 +157,9 @@ _lock = threading.Lock()
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # TADMM_LIB: file name of an instrumented build of the same sources next to the product library (e.g. the
+    # -DTADMM_TRI_STAMPS variant scripts/stamp_tri.py uses); never a fallback -- a missing file still raises
+    return os.path.join(_HERE, os.path.basename(os.environ.get("TADMM_LIB", _LIB_NAME)))
 
 
 def load():
