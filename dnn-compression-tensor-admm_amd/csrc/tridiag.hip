@@ -74,66 +74,64 @@ __device__ __forceinline__ double hash_pm1(uint32_t a, uint32_t b) {
   return (double)(int64_t)(x >> 11) * (1.0 / 4503599627370496.0) - 1.0;
 }
 
-// number of eigenvalues of the (scaled) tridiagonal below x: sign changes of p_0 = 1, p_i = det(T_i - x I).
-// Product form -- one FMA per step on the dependent chain instead of a division -- with the pair (p_{i-1}, p_i)
-// rescaled every 8 steps; an exact zero counts as a sign change (the sign opposite to its predecessor).
-__device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const double* __restrict__ e2s, int n, double x) {
-  double p0 = 1.0, p1 = ds[0] - x;
-  int cnt = (p1 <= 0.0) ? 1 : 0;
-  if (p1 == 0.0) p1 = -1e-300;
-  for (int i = 1; i < n; ++i) {
-    double p2 = (ds[i] - x) * p1 - e2s[i - 1] * p0;
-    if (p2 == 0.0) p2 = (p1 < 0.0) ? 1e-300 : -1e-300;
-    cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
-    p0 = p1; p1 = p2;
-    if ((i & 7) == 0) {
-      const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(p0), fabs(p1)));
-      p0 = __builtin_amdgcn_ldexp(p0, -ex);
-      p1 = __builtin_amdgcn_ldexp(p1, -ex);
-      if (p1 == 0.0) p1 = (p0 < 0.0) ? 1e-300 : -1e-300;       // (underflow of the smaller one)
-    }
-  }
-  return cnt;
-}
-
 #ifdef TADMM_TRI_STAMPS
 __device__ long long g_tri_stamps[16];
 #define TSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tri_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TSUB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long tnow = (long long)__builtin_readcyclecounter(); g_tri_stamps[8 + i] += tnow - tsub; tsub = tnow; } } while (0)
 #else
 #define TSTAMP(i) do { } while (0)
+#define TSUB(i) do { } while (0)
 #endif
 
 }  // namespace
 
-// Dynamic LDS (doubles): Hv[64][65] | Z[64][65] | LUa[64][64] | LUb[64][64] | vectors
-constexpr int kTVecDoubles = 12 * kTN + 64;
-constexpr size_t kTLdsBytes = ((size_t)2 * kTN * kTLd + 2 * kTN * kTN + kTVecDoubles) * sizeof(double);
+// ~2^-24 relative from v_rcp_f64 / v_rsq_f64, two Newton steps each: full fp64 without the IEEE division sequence
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {      // x > 0
+  const double r = fast_rsqrt(x);
+  const double s = x * r;
+  return fma(fma(-s, s, x), 0.5 * r, s);
+}
 
-__global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __restrict__ descs,
-                                                               const int32_t* __restrict__ skip,
-                                                               int32_t* __restrict__ fast_done, int* __restrict__ verdict) {
-  extern __shared__ __attribute__((aligned(16))) double tsm[];
-  const int p = blockIdx.x;
+// Dynamic LDS (doubles): Hv[64][66] | Z[64][66] | LUa[64][64] | LUb[64][64] | vectors
+constexpr int kTLdv = kTN + 2;       // even leading dimension: rows are 16-byte aligned (b128 reads of row pieces)
+constexpr int kTVecDoubles = 12 * kTN + 64;
+constexpr size_t kTLdsBytes = ((size_t)2 * kTN * kTLdv + 2 * kTN * kTN + kTVecDoubles) * sizeof(double);
+
+// NS: padded size of the tridiagonal phases (32 or 64).  Beyond n the tridiagonal is padded with diagonal entries far
+// below the (scaled) spectrum and zero couplings: a decoupled block whose eigenvalues are never among the leading ones
+// and whose eigenvector entries stay exactly zero -- every loop of phases 2-4 then has a compile-time trip count and
+// the vectors live in registers with static indices.
+template <int NS>
+__device__ __forceinline__ void eig_small_direct_body(const EigDesc& d, int p, double* __restrict__ tsm,
+                                                      int32_t* __restrict__ fast_done, int* __restrict__ verdict) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) fast_done[p] = 0;
-  if (skip && skip[p]) return;                       // jacobi_small_kernel, launched behind this one, does the bookkeeping
-  const EigDesc d = descs[p];
   const int n = d.N, ld = d.ld;
-  if (n < 3 || n > kTN) return;
-  double (*Hv)[kTLd] = reinterpret_cast<double (*)[kTLd]>(tsm);
-  double (*Z)[kTLd] = Hv + kTN;
-  double* LUa = tsm + 2 * kTN * kTLd;                // [k][j]: reciprocal pivots
+  double (*Hv)[kTLdv] = reinterpret_cast<double (*)[kTLdv]>(tsm);
+  double (*Z)[kTLdv] = Hv + kTN;
+  double* LUa = tsm + 2 * kTN * kTLdv;               // [k][j]: reciprocal pivots
   double* LUb = LUa + kTN * kTN;                     // [k][j]: super-diagonal after elimination
   double* vec = LUb + kTN * kTN;
   double* dd = vec;            // [64] diagonal of T
   double* ee = dd + kTN;       // [64] sub-diagonal
-  double* ds = ee + kTN;       // [64] scaled diagonal
-  double* e2s = ds + kTN;      // [64] scaled squared sub-diagonal
-  double* tauv = e2s + kTN;    // [64]
+  double* ds = ee + kTN;       // [64] scaled diagonal (padded)
+  double* es = ds + kTN;       // [64] scaled sub-diagonal (zero from n-1 on)
+  double* tauv = es + kTN;     // [64]
   double* xs = tauv + kTN;     // [64] column being eliminated
   double* vs = xs + kTN;       // [64] Householder vector
   double* ps = vs + kTN;       // [64] A v
-  double* lam = ps + kTN;      // [64] eigenvalues (descending)
+  double* lam = ps + kTN;      // [64] eigenvalues (descending, scaled)
   double* theta = lam + kTN;   // [64] Rayleigh quotients
   double* red = theta + kTN;   // [64] scratch
   int* ivec = reinterpret_cast<int*>(red + kTN);     // [128] ints: cluster start, flags
@@ -151,10 +149,14 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
       a[r][c] = (i < n && j < n) ? XT[(int64_t)i * ld + j] : 0.0;
     }
   if (tid < kTN) { dd[tid] = 0.0; ee[tid] = 0.0; tauv[tid] = 0.0; }
-  for (int idx = tid; idx < kTN * kTLd; idx += 256) (&Hv[0][0])[idx] = 0.0;
+  for (int idx = tid; idx < kTN * kTLdv; idx += 256) (&Hv[0][0])[idx] = 0.0;
   __syncthreads();
 
   TSTAMP(1);
+#ifdef TADMM_TRI_STAMPS
+  long long tsub = (long long)__builtin_readcyclecounter();
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 8; q < 16; ++q) g_tri_stamps[q] = 0;
+#endif
   // ---- 1. Householder tridiagonalisation (dsytd2, lower) ----
   for (int kb = 0; kb < 16; ++kb) {
     if (4 * kb >= n - 2) break;
@@ -163,20 +165,21 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
       const int k = 4 * kb + kk;
       if (k >= n - 2) break;                          // uniform
       if (Cc == kb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xs[4 * R + r] = a[r][kk];
+        *reinterpret_cast<double2_t*>(&xs[4 * R]) = double2_t{a[0][kk], a[1][kk]};
+        *reinterpret_cast<double2_t*>(&xs[4 * R + 2]) = double2_t{a[2][kk], a[3][kk]};
         if (R == kb) dd[k] = a[kk][kk];
       }
       __syncthreads();
+      TSUB(0);
       // every wave forms the reflector redundantly (lane l <-> row l)
       const double x = (lane > k) ? xs[lane] : 0.0;
       const double alpha = xs[k + 1];
       const double xn2 = wave_sum((lane > k + 1) ? x * x : 0.0);
       double tau = 0.0, beta = alpha, v = (lane == k + 1) ? 1.0 : 0.0;
-      if (xn2 > 0.0) {
-        beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
-        tau = (beta - alpha) / beta;
-        const double sc = 1.0 / (alpha - beta);
+      if (xn2 > 0.0) {                                // uniform
+        beta = -copysign(fast_sqrt(fma(alpha, alpha, xn2)), alpha);
+        tau = (beta - alpha) * fast_rcp(beta);
+        const double sc = fast_rcp(alpha - beta);
         if (lane > k + 1) v = x * sc;
       }
       vs[lane] = v;
@@ -185,40 +188,58 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
         if (lane == 0) { ee[k] = beta; tauv[k] = tau; }
       }
       wave_fence();
+      TSUB(1);
       if (tau != 0.0) {                               // uniform
         double vr[4], vc[4], pr[4];
+        {
+          const double2_t r0 = *reinterpret_cast<const double2_t*>(&vs[4 * R]), r1 = *reinterpret_cast<const double2_t*>(&vs[4 * R + 2]);
+          const double2_t c0 = *reinterpret_cast<const double2_t*>(&vs[4 * Cc]), c1 = *reinterpret_cast<const double2_t*>(&vs[4 * Cc + 2]);
+          vr[0] = r0.x; vr[1] = r0.y; vr[2] = r1.x; vr[3] = r1.y;
+          vc[0] = c0.x; vc[1] = c0.y; vc[2] = c1.x; vc[3] = c1.y;
+        }
+        double t4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { vr[r] = vs[4 * R + r]; vc[r] = vs[4 * Cc + r]; }
+        for (int r = 0; r < 4; ++r) t4[r] = (a[r][0] * vc[0] + a[r][1] * vc[1]) + (a[r][2] * vc[2] + a[r][3] * vc[3]);
+        // four independent reductions over the 16 lanes of the row group, stage by stage (the DPP latencies overlap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] += tdpp<0xB1>(t4[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] += tdpp<0x4E>(t4[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] += tdpp<0x141>(t4[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t4[r] += tdpp<0x140>(t4[r]);
         double s = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double t = 0.0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) t += a[r][c] * vc[c];
-          t = row16_sum(t);
-          pr[r] = (4 * R + r > k) ? t : 0.0;          // rows <= k are finished: keep them out of the update
+          pr[r] = (4 * R + r > k) ? t4[r] : 0.0;      // rows <= k are finished: keep them out of the update
           s += vr[r] * pr[r];
         }
+        // v^T A v: one value per 16-lane row group -> per wave -> LDS
+        const double sw = (readlane_f64(s, 0) + readlane_f64(s, 16)) + (readlane_f64(s, 32) + readlane_f64(s, 48));
         if (Cc == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ps[4 * R + r] = pr[r];
-          red[R] = s;
+          *reinterpret_cast<double2_t*>(&ps[4 * R]) = double2_t{pr[0], pr[1]};
+          *reinterpret_cast<double2_t*>(&ps[4 * R + 2]) = double2_t{pr[2], pr[3]};
         }
+        if (lane == 0) red[wave] = sw;
+        TSUB(2);
         __syncthreads();
-        double vav = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) vav += red[q];
-        const double K = 0.5 * tau * tau * vav;
+        TSUB(3);
+        const double2_t q0 = *reinterpret_cast<const double2_t*>(&red[0]), q1 = *reinterpret_cast<const double2_t*>(&red[2]);
+        const double K = 0.5 * tau * tau * ((q0.x + q0.y) + (q1.x + q1.y));
+        const double2_t p0 = *reinterpret_cast<const double2_t*>(&ps[4 * Cc]), p1 = *reinterpret_cast<const double2_t*>(&ps[4 * Cc + 2]);
+        const double pc[4] = {p0.x, p0.y, p1.x, p1.y};
         double wr[4], wc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           wr[r] = tau * pr[r] - K * vr[r];
-          wc[r] = tau * ps[4 * Cc + r] - K * vc[r];
+          wc[r] = tau * pc[r] - K * vc[r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int c = 0; c < 4; ++c) a[r][c] -= vr[r] * wc[c] + wr[r] * vc[c];
+        TSUB(4);
       } else {
         __syncthreads();                              // keep two barriers per step: a wave must not start step k+1 (new xs /
       }                                               // vs) while another one still reads this step's
@@ -242,40 +263,78 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
   }
 
   TSTAMP(2);
-  // ---- 2. scale, bisection for the leading rw eigenvalues ----
+  // ---- 2. scale + pad, bisection for the leading rw eigenvalues ----
   const int rw = min(n, max(1, d.r) + 2);
   double tn;
   {
     double g = 0.0;
     if (lane < n) g = fabs(dd[lane]) + (lane > 0 ? fabs(ee[lane - 1]) : 0.0) + (lane < n - 1 ? fabs(ee[lane]) : 0.0);
-    // max over the wave (values >= 0): reuse the sum helpers on a max
     g = fmax(g, tdpp<0xB1>(g)); g = fmax(g, tdpp<0x4E>(g)); g = fmax(g, tdpp<0x141>(g)); g = fmax(g, tdpp<0x140>(g));
     tn = fmax(fmax(readlane_f64(g, 0), readlane_f64(g, 16)), fmax(readlane_f64(g, 32), readlane_f64(g, 48)));
   }
   if (!(tn > 0.0) || !(tn < 1e300)) return;           // zero / non-finite matrix: the Jacobi path decides (uniform)
   const double itn = 1.0 / tn;
+  double* e2p = xs;            // [64] squared coupling in FRONT of row i: (e_{i-1}/tn)^2, 0 for i = 0 (xs is free now)
   if (tid < kTN) {
-    ds[tid] = tid < n ? dd[tid] * itn : 0.0;
-    const double es = tid < n - 1 ? ee[tid] * itn : 0.0;
-    e2s[tid] = es * es;
+    ds[tid] = tid < n ? dd[tid] * itn : -8.0;         // padding: decoupled entries far below the spectrum [-1, 1]
+    es[tid] = tid < n - 1 ? ee[tid] * itn : 0.0;
+    const double ep = (tid > 0 && tid < n) ? ee[tid - 1] * itn : 0.0;
+    e2p[tid] = ep * ep;
   }
   __syncthreads();
+  // the scaled tridiagonal is read from LDS eight entries at a time (every lane the same address: broadcast reads), the
+  // next block requested before the current one is consumed: the dependent chains below never wait for a load
+  auto load8 = [&](const double* src, double* dst) {
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      const double2_t t = *reinterpret_cast<const double2_t*>(&src[u]);
+      dst[u] = t.x; dst[u + 1] = t.y;
+    }
+  };
   {
-    // P probes per eigenvalue, the P lanes of an eigenvalue adjacent; eigenvalue j (descending) has kth = n-1-j below it
+    // number of eigenvalues of the padded tridiagonal below x: sign changes of p_0 = 1, p_i = det(T_i - x I).  Product
+    // form -- ONE FMA per step on the dependent chain instead of a division -- with the pair (p_{i-1}, p_i) rescaled
+    // every 8 steps; an exact zero counts as a sign change (the sign opposite to its predecessor).
+    auto sturm = [&](double x) -> int {
+      double dv[8], ev[8], dn[8], en[8];
+      load8(ds, dv); load8(e2p, ev);
+      double p0 = 1.0, p1 = 1.0;
+      int cnt = 0;
+#pragma unroll
+      for (int b = 0; b < NS / 8; ++b) {
+        if (b + 1 < NS / 8) { load8(ds + 8 * (b + 1), dn); load8(e2p + 8 * (b + 1), en); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          // (block 0, u = 0: p_1 = (d_0 - x) * 1 - 0.)  An exact zero needs no special case: its successor is -e^2 p_{i-1},
+          // of the sign opposite to its predecessor, and the two comparisons below count exactly one change for the pair
+          const double p2 = fma(dv[u] - x, p1, -ev[u] * p0);
+          cnt += ((p2 < 0.0) != (p1 < 0.0)) ? 1 : 0;
+          p0 = p1; p1 = p2;
+        }
+        const int ex = __builtin_amdgcn_frexp_exp(fmax(fabs(p0), fabs(p1)));
+        p0 = __builtin_amdgcn_ldexp(p0, -ex);
+        p1 = __builtin_amdgcn_ldexp(p1, -ex);
+        if (p1 == 0.0) p1 = (p0 < 0.0) ? 1e-300 : -1e-300;       // (underflow of the smaller one)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dv[u] = dn[u]; ev[u] = en[u]; }
+      }
+      return cnt;
+    };
+    // P probes per eigenvalue, the P lanes of an eigenvalue adjacent; eigenvalue j (descending) has kth = NS-1-j below it
     const int P = rw <= 16 ? 16 : (rw <= 32 ? 8 : 4);
     const int j = tid / P, pi = tid - j * P;
     const bool act = j < rw;
-    const int kth = n - 1 - j;
+    const int kth = NS - 1 - j;
     double lo = -1.0 - 1e-12, hi = 1.0 + 1e-12;      // Gershgorin bounds of the scaled matrix
     const int rounds = P == 16 ? 11 : (P == 8 ? 14 : 19);      // >= 44 bits
     const double step = 1.0 / (P + 1);
     for (int it = 0; it < rounds; ++it) {
       const double xq = lo + (hi - lo) * ((pi + 1) * step);
-      const int c = act ? sturm_count(ds, e2s, n, xq) : 0;
+      const int c = sturm(xq);
       const bool le = c <= kth;                       // the probe is still <= lambda_j
       const unsigned long long m = __ballot(le);
       const int base = (lane / P) * P;
-      const unsigned long long grp = (m >> base) & ((P == 64) ? ~0ull : ((1ull << P) - 1ull));
+      const unsigned long long grp = (m >> base) & ((1ull << P) - 1ull);
       const int cntle = __popcll(grp);                // counts are monotone in x: the first cntle probes are <= lambda_j
       const double w = hi - lo;
       const double nlo = cntle > 0 ? lo + w * (cntle * step) : lo;
@@ -287,7 +346,7 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
   __syncthreads();
 
   TSTAMP(3);
-  // ---- 3. clusters, inverse iteration (one thread per eigenvector) ----
+  // ---- 3. clusters, inverse iteration (one thread per eigenvector, the vector in registers) ----
   int* cstart = ivec;              // [64]
   int* flags = ivec + 64;          // [0] max cluster position, [1] failure
   if (tid == 0) {
@@ -309,100 +368,148 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
     double shift = act ? lam[j] : 0.0;
     if (act && pos > 0) {                             // keep the shifts of a cluster apart (dstein)
       const double sep = 10.0 * 2.220446049250313e-16;
-      // shifts inside a cluster must be strictly decreasing by at least sep: cumulative from the cluster start
       double prev = lam[st];
       for (int i = st + 1; i <= j; ++i) prev = fmin(lam[i], prev - sep);
       shift = prev;
     }
     const double tol = 2.220446049250313e-16;         // pivot floor (scaled matrix: ||T|| ~ 1)
-    if (act)
-      for (int i = 0; i < n; ++i) Z[j][i] = hash_pm1((uint32_t)p * 2654435761u + 101u, (uint32_t)(j * kTN + i));
+    double x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      x[i] = (act && i < n) ? hash_pm1((uint32_t)p * 2654435761u + 101u, (uint32_t)(j * kTN + i)) : 0.0;
     for (int iter = 0; iter < 2; ++iter) {
       if (act) {
-        // forward elimination with partial pivoting on rows (k, k+1); the right-hand side rides along
-        const double* es = ee;                        // unscaled sub-diagonal; scaled on the fly
-        double ak = ds[0] - shift;                    // current diagonal entry of row k
-        double bk = n > 1 ? es[0] * itn : 0.0;        // current super-diagonal entry of row k
-        double xk = Z[j][0];
+        // forward elimination with partial pivoting on rows (k, k+1); the right-hand side rides along in x
+        double db[8], eb[8], dnx[8], enx[8];
+        load8(ds, db); load8(es, eb);                 // db[u] = d_{8b+u}, eb[u] = e_{8b+u} (coupling of rows 8b+u, 8b+u+1)
+        double ak = db[0] - shift;                    // current diagonal entry of row k
+        double bk = eb[0];                            // current super-diagonal entry of row k
+        double xk = x[0];
         unsigned long long swapped = 0ull;
-        for (int k = 0; k < n - 1; ++k) {
-          const double ck = es[k] * itn;              // sub-diagonal entry of row k+1
-          const double ak1 = ds[k + 1] - shift;
-          const double bk1 = (k + 1 < n - 1) ? es[k + 1] * itn : 0.0;
-          double xk1 = Z[j][k + 1];
-          if (fabs(ak) >= fabs(ck)) {
-            double piv = ak;
-            if (!(fabs(piv) > tol)) piv = (piv < 0.0) ? -tol : tol;
-            const double ip = 1.0 / piv;
-            const double m = ck * ip;
-            LUa[k * kTN + j] = ip; LUb[k * kTN + j] = bk;
-            Z[j][k] = xk;
-            ak = ak1 - m * bk; bk = bk1; xk = xk1 - m * xk;
-          } else {                                    // interchange rows k and k+1
-            const double ip = 1.0 / ck;
-            const double m = ak * ip;
-            LUa[k * kTN + j] = ip; LUb[k * kTN + j] = ak1;
-            swapped |= 1ull << k;
-            Z[j][k] = xk1;
-            ak = bk - m * ak1; bk = -m * bk1; xk = xk - m * xk1;
+#pragma unroll
+        for (int b = 0; b < NS / 8; ++b) {
+          if (b + 1 < NS / 8) { load8(ds + 8 * (b + 1), dnx); load8(es + 8 * (b + 1), enx); }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = 8 * b + u;
+            if (k < NS - 1) {
+              const double ck = eb[u];                                       // sub-diagonal entry of row k+1
+              const double ak1 = ((u < 7) ? db[u + 1] : dnx[0]) - shift;
+              const double bk1 = (k + 1 < NS - 1) ? ((u < 7) ? eb[u + 1] : enx[0]) : 0.0;
+              const double xk1 = x[k + 1];
+              // branch-free (the lanes of a wave disagree about interchanges: both sides of a branch would run)
+              const bool sw = fabs(ak) < fabs(ck);    // interchange rows k and k+1
+              double piv = sw ? ck : ak;
+              if (!(fabs(piv) > tol)) piv = (piv < 0.0) ? -tol : tol;
+              const double ip = fast_rcp(piv);
+              const double m = (sw ? ak : ck) * ip;
+              LUa[k * kTN + j] = ip; LUb[k * kTN + j] = sw ? ak1 : bk;
+              swapped |= sw ? (1ull << k) : 0ull;
+              x[k] = sw ? xk1 : xk;
+              const double na = fma(-m, sw ? ak1 : bk, sw ? bk : ak1);
+              const double nx = fma(-m, sw ? xk1 : xk, sw ? xk : xk1);
+              bk = sw ? -m * bk1 : bk1;
+              ak = na; xk = nx;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { db[u] = dnx[u]; eb[u] = enx[u]; }
+        }
+        double piv = ak;
+        if (!(fabs(piv) > tol)) piv = (piv < 0.0) ? -tol : tol;
+        // back substitution: row k = (piv_k, LUb_k, swapped_k ? e_{k+1} : 0); the stored factors come back in blocks of 8
+        double x2 = 0.0, x1 = xk * fast_rcp(piv);
+        x[NS - 1] = x1;
+        double mx = fabs(x1);
+#pragma unroll
+        for (int b = NS / 8 - 1; b >= 0; --b) {
+          double la[8], lb[8], e1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = 8 * b + u;
+            la[u] = (k < NS - 1) ? LUa[k * kTN + j] : 0.0;
+            lb[u] = (k < NS - 1) ? LUb[k * kTN + j] : 0.0;
+            e1[u] = (k + 1 < NS - 1) ? es[k + 1] : 0.0;
+          }
+#pragma unroll
+          for (int u = 7; u >= 0; --u) {
+            const int k = 8 * b + u;
+            if (k < NS - 1) {
+              const double s2 = ((swapped >> k) & 1ull) ? e1[u] : 0.0;
+              const double xv = (x[k] - lb[u] * x1 - s2 * x2) * la[u];
+              x[k] = xv;
+              x2 = x1; x1 = xv;
+              mx = fmax(mx, fabs(xv));
+            }
           }
         }
-        {
-          double piv = ak;
-          if (!(fabs(piv) > tol)) piv = (piv < 0.0) ? -tol : tol;
-          LUa[(n - 1) * kTN + j] = 1.0 / piv;
-        }
-        // back substitution: row k = (piv_k, LUb_k, swapped_k ? e_{k+1} : 0)
-        double x2 = 0.0, x1 = xk * LUa[(n - 1) * kTN + j];
-        Z[j][n - 1] = x1;
-        for (int k = n - 2; k >= 0; --k) {
-          const double s2 = ((swapped >> k) & 1ull) && (k + 1 < n - 1) ? es[k + 1] * itn : 0.0;
-          const double xv = (Z[j][k] - LUb[k * kTN + j] * x1 - s2 * x2) * LUa[k * kTN + j];
-          Z[j][k] = xv;
-          x2 = x1; x1 = xv;
-        }
         // overflow guard + normalisation (cluster members are re-normalised after their orthogonalisation)
-        double mx = 0.0;
-        for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(Z[j][i]));
-        const double sc = (mx > 0.0 && mx < 1e300) ? 1.0 / mx : 0.0;
-        double nn = 0.0;
-        for (int i = 0; i < n; ++i) { const double t = Z[j][i] * sc; nn += t * t; }
-        const double inv = nn > 0.0 ? sc / sqrt(nn) : 0.0;
+        const double sc = (mx > 0.0 && mx < 1e300) ? fast_rcp(mx) : 0.0;
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; i += 4) {
+          const double t0 = x[i] * sc, t1 = x[i + 1] * sc, t2 = x[i + 2] * sc, t3 = x[i + 3] * sc;
+          n0 = fma(t0, t0, n0); n1 = fma(t1, t1, n1); n2 = fma(t2, t2, n2); n3 = fma(t3, t3, n3);
+        }
+        const double nn = (n0 + n1) + (n2 + n3);
+        const double inv = nn > 0.0 ? sc * fast_rsqrt(nn) : 0.0;
         if (!(inv > 0.0)) flags[1] = 1;
-        for (int i = 0; i < n; ++i) Z[j][i] *= inv;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] *= inv;
+#pragma unroll
+        for (int i = 0; i < NS; i += 2) *reinterpret_cast<double2_t*>(&Z[j][i]) = double2_t{x[i], x[i + 1]};
       }
       __syncthreads();
-      for (int q = 1; q <= maxpos; ++q) {             // modified Gram-Schmidt inside clusters, in order
+      for (int q = 1; q <= maxpos; ++q) {             // modified Gram-Schmidt inside clusters, in order (rare, short)
         if (act && pos == q) {
           for (int i = st; i < j; ++i) {
             double dot = 0.0;
-            for (int t = 0; t < n; ++t) dot += Z[i][t] * Z[j][t];
-            for (int t = 0; t < n; ++t) Z[j][t] -= dot * Z[i][t];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) dot = fma(Z[i][t], x[t], dot);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) x[t] = fma(-dot, Z[i][t], x[t]);
           }
           double nn = 0.0;
-          for (int t = 0; t < n; ++t) nn += Z[j][t] * Z[j][t];
-          const double inv = nn > 1e-20 ? 1.0 / sqrt(nn) : 0.0;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) nn = fma(x[t], x[t], nn);
+          const double inv = nn > 1e-20 ? fast_rsqrt(nn) : 0.0;
           if (!(inv > 0.0)) flags[1] = 1;
-          for (int t = 0; t < n; ++t) Z[j][t] *= inv;
+#pragma unroll
+          for (int t = 0; t < NS; ++t) { x[t] *= inv; Z[j][t] = x[t]; }
         }
         __syncthreads();
       }
     }
     TSTAMP(4);
-    // ---- 4. Rayleigh quotients (unscaled), residuals, orthogonality against the neighbours ----
+    // ---- 4. Rayleigh quotients (unscaled) and residuals ----
     if (act) {
-      double th = 0.0;
-      for (int i = 0; i < n; ++i) {
-        const double zi = Z[j][i];
-        th += ds[i] * zi * zi;
-        if (i + 1 < n) th += 2.0 * (ee[i] * itn) * zi * Z[j][i + 1];
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int b = 0; b < NS / 8; ++b) {
+        double db[8], eb[8];
+        load8(ds + 8 * b, db); load8(es + 8 * b, eb);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = 8 * b + u;
+          t0 = fma(db[u] * x[i], x[i], t0);
+          if (i + 1 < NS) t1 = fma(eb[u] * x[i], x[i + 1], t1);
+        }
       }
+      const double th = t0 + 2.0 * t1;
       double rmax = 0.0;
-      for (int i = 0; i < n; ++i) {
-        double t = (ds[i] - th) * Z[j][i];
-        if (i > 0) t += (ee[i - 1] * itn) * Z[j][i - 1];
-        if (i + 1 < n) t += (ee[i] * itn) * Z[j][i + 1];
-        rmax = fmax(rmax, fabs(t));
+#pragma unroll
+      for (int b = 0; b < NS / 8; ++b) {
+        double db[8], eb[8];
+        load8(ds + 8 * b, db); load8(es + 8 * b, eb);
+        const double eprev = b > 0 ? es[8 * b - 1] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = 8 * b + u;
+          double t = (db[u] - th) * x[i];
+          if (i > 0) t = fma(u > 0 ? eb[u - 1] : eprev, x[i - 1], t);
+          if (i + 1 < NS) t = fma(eb[u], x[i + 1], t);
+          rmax = fmax(rmax, fabs(t));
+        }
       }
       if (!(rmax <= 1e-13) || th != th) flags[1] = 1;
       theta[j] = th * tn;
@@ -413,11 +520,21 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
   {   // orthogonality of ALL computed pairs (inverse iteration gives no guarantee): thread (j, quarter) takes i = quarter, +4, ...
     const int j = tid & 63, q4 = tid >> 6;
     if (j < rw) {
+      double zj[NS];
+#pragma unroll
+      for (int t = 0; t < NS; t += 2) {
+        const double2_t v2 = *reinterpret_cast<const double2_t*>(&Z[j][t]);
+        zj[t] = v2.x; zj[t + 1] = v2.y;
+      }
       double worst = 0.0;
       for (int i = q4; i < j; i += 4) {
-        double dot = 0.0;
-        for (int t = 0; t < n; ++t) dot += Z[i][t] * Z[j][t];
-        worst = fmax(worst, fabs(dot));
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NS; t += 4) {
+          const double2_t v2 = *reinterpret_cast<const double2_t*>(&Z[i][t]), v3 = *reinterpret_cast<const double2_t*>(&Z[i][t + 2]);
+          d0 = fma(v2.x, zj[t], d0); d1 = fma(v2.y, zj[t + 1], d1); d2 = fma(v3.x, zj[t + 2], d2); d3 = fma(v3.y, zj[t + 3], d3);
+        }
+        worst = fmax(worst, fabs((d0 + d1) + (d2 + d3)));
       }
       if (!(worst <= 1e-11)) flags[1] = 1;
     }
@@ -432,23 +549,45 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
     const bool act = j < rw;
     double u[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) u[c] = act ? Z[j][16 * part + c] : 0.0;
-    for (int k = n - 3; k >= 0; --k) {
-      const double tau = tauv[k];
-      if (tau == 0.0) continue;                       // uniform
-      double dot = 0.0;
-      const double* hv = &Hv[k][16 * part];
-      if (16 * part + 15 > k) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) dot += hv[c] * u[c];
-      }
-      dot = quad_sum(dot) * tau;
-      if (16 * part + 15 > k) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) u[c] -= dot * hv[c];
-      }
+    for (int c = 0; c < 16; c += 2) {
+      const double2_t v2 = *reinterpret_cast<const double2_t*>(&Z[j][16 * part + c]);
+      u[c] = (act && 16 * part + c < NS) ? v2.x : 0.0;          // (Z rows hold NS entries)
+      u[c + 1] = (act && 16 * part + c + 1 < NS) ? v2.y : 0.0;
     }
-    __syncthreads();                                  // every read of the input image happened long ago; now overwrite it
+    double hv[16];
+    auto load_hv = [&](int k) {
+#pragma unroll
+      for (int c = 0; c < 16; c += 2) {
+        const double2_t v2 = *reinterpret_cast<const double2_t*>(&Hv[k][16 * part + c]);
+        hv[c] = v2.x; hv[c + 1] = v2.y;
+      }
+    };
+    double taun = 0.0;
+    if (n >= 3) { load_hv(n - 3); taun = tauv[n - 3]; }
+    for (int k = n - 3; k >= 0; --k) {
+      const double tau = taun;
+      double h[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) h[c] = hv[c];
+      if (k > 0) { load_hv(k - 1); taun = tauv[k - 1]; }     // next reflector on its way while this one is applied
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c += 4) {
+        d0 = fma(h[c], u[c], d0); d1 = fma(h[c + 1], u[c + 1], d1); d2 = fma(h[c + 2], u[c + 2], d2); d3 = fma(h[c + 3], u[c + 3], d3);
+      }
+      const double dot = quad_sum((d0 + d1) + (d2 + d3)) * tau;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) u[c] = fma(-dot, h[c], u[c]);
+    }
+    {   // last check before the image is overwritten: the back-transformed vectors are unit vectors (finite!)
+      double nn = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) nn = fma(u[c], u[c], nn);
+      nn = quad_sum(nn);
+      if (act && !(fabs(nn - 1.0) <= 1e-9)) flags[1] = 1;
+    }
+    __syncthreads();                                  // (also: every read of the input image happened long ago)
+    if (flags[1]) return;                             // uniform
     const int Npad = d.Npad;
     if (j < Npad) {
       const double sc = act ? theta[j] : 0.0;
@@ -467,6 +606,19 @@ __global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __
     __threadfence();
     fast_done[p] = 1;
   }
+}
+
+__global__ __launch_bounds__(256) void eig_small_direct_kernel(const EigDesc* __restrict__ descs,
+                                                               const int32_t* __restrict__ skip,
+                                                               int32_t* __restrict__ fast_done, int* __restrict__ verdict) {
+  extern __shared__ __attribute__((aligned(16))) double tsm[];
+  const int p = blockIdx.x;
+  if (threadIdx.x == 0) fast_done[p] = 0;
+  if (skip && skip[p]) return;                       // jacobi_small_kernel, launched behind this one, does the bookkeeping
+  const EigDesc d = descs[p];
+  if (d.N < 3 || d.N > kTN) return;
+  if (d.N <= 32) eig_small_direct_body<32>(d, p, tsm, fast_done, verdict);
+  else eig_small_direct_body<64>(d, p, tsm, fast_done, verdict);
 }
 
 bool eig_small_direct_on() {
@@ -493,8 +645,9 @@ void launch_eig_small_direct(const EigDesc* descs_dev, int nprob, const int32_t*
     long long h[16];
     (void)hipStreamSynchronize(s);
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tri_stamps), sizeof h) == hipSuccess)
-      fprintf(stderr, "[tri stamps] cycles: load=%lld tridiag=%lld bisect=%lld invit=%lld rq=%lld orth=%lld back=%lld total=%lld\n",
-              h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+      fprintf(stderr, "[tri stamps] cycles: load=%lld tridiag=%lld bisect=%lld invit=%lld rq=%lld orth=%lld back=%lld total=%lld | tridiag: xs+barrier=%lld reflector=%lld matvec=%lld barrier=%lld update=%lld\n",
+              h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0],
+              h[8], h[9], h[10], h[11], h[12]);
   }
 #endif
 }
