@@ -67,7 +67,9 @@ __device__ __forceinline__ void store_tile4(float* __restrict__ S, int ldS, bool
   }
 }
 
-// one 64x64 output tile (`local` = tile index inside the problem)
+// one 64x64 output tile (`local` = tile index inside the problem).  kComp: chunked accumulation with an fp64 total
+// (the product default); false = one fp32 accumulator over all of K (TADMM_GEMM_PLAIN=1: A/B measurements only)
+template <bool kComp>
 __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* __restrict__ As, float* __restrict__ Bs) {
   const int tm = local / d.tiles_n, tn = local - tm * d.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -87,6 +89,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
   float16_t acc0 = zero16, acc1 = zero16;
   double16_t tot = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto fold = [&](float16_t& a) {
+    if (!kComp) return;
 #pragma unroll
     for (int e = 0; e < 16; ++e) tot[e] += (double)a[e];
     a = zero16;
@@ -116,17 +119,17 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
     __syncthreads();
     if (k0 + BK < K) { step(k0 + BK, acc0); __syncthreads(); }
     if (k0 + 2 * BK < K) {
-      step(k0 + 2 * BK, acc1);
+      step(k0 + 2 * BK, kComp ? acc1 : acc0);
       fold(acc0);
       __syncthreads();
-      if (k0 + 3 * BK < K) { step(k0 + 3 * BK, acc1); __syncthreads(); }
+      if (k0 + 3 * BK < K) { step(k0 + 3 * BK, kComp ? acc1 : acc0); __syncthreads(); }
     }
   }
   fold(acc0);
   fold(acc1);
   float16_t acc;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = (float)tot[e];
+  for (int e = 0; e < 16; ++e) acc[e] = kComp ? (float)tot[e] : acc0[e];
 
   // epilogue: D row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
   const int col = n0 + wn * 32 + (lane & 31);
@@ -146,6 +149,7 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
   }
 }
 
+template <bool kComp>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ descs,
                                                    const BlockRef* __restrict__ map,
                                                    const int32_t* __restrict__ skip) {
@@ -154,26 +158,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc* __restrict__ 
   const BlockRef br = map[blockIdx.x];
   if (skip && skip[br.prob]) return;
   const GemmDesc d = descs[br.prob];
-  gemm_tile(d, br.local, As, Bs);
+  gemm_tile<kComp>(d, br.local, As, Bs);
 }
 
 // A single GEMM whose descriptor travels as a kernel argument: no descriptor upload, no block map
 // (the per-call path of the factorised layers' forward / backward products).
+template <bool kComp>
 __global__ __launch_bounds__(256) void gemm_one_kernel(const GemmDesc d) {
   __shared__ __attribute__((aligned(16))) float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  gemm_tile(d, blockIdx.x, As, Bs);
+  gemm_tile<kComp>(d, blockIdx.x, As, Bs);
+}
+
+static bool gemm_plain() {
+  const char* e = getenv("TADMM_GEMM_PLAIN");
+  return e && atoi(e);
 }
 
 void launch_gemm_one(const GemmDesc& d, hipStream_t s) {
   const int nblocks = d.tiles_m * d.tiles_n;
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(gemm_one_kernel, dim3(nblocks), dim3(256), 0, s, d);
+  if (gemm_plain()) hipLaunchKernelGGL(gemm_one_kernel<false>, dim3(nblocks), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(gemm_one_kernel<true>, dim3(nblocks), dim3(256), 0, s, d);
 }
 
 void launch_gemm(const GemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, const int32_t* skip) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(gemm_kernel, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
+  if (gemm_plain()) hipLaunchKernelGGL(gemm_kernel<false>, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
+  else hipLaunchKernelGGL(gemm_kernel<true>, dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev, skip);
 }
 
 }  // namespace tadmm
