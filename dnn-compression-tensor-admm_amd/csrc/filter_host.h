@@ -16,8 +16,18 @@ static inline int filter_block_size(int N, int r) {
   if (N < min_n || r < 16) return 0;
   double over = 1.55;
   if (const char* o = getenv("TADMM_FILTER_OVERSAMPLE")) over = atof(o);
-  const int rp = (int)align_up((size_t)(over * r + 0.999), 32);
-  if (rp > 256 || rp * 100 > 56 * N || rp <= r) return 0;
+  int rp = (int)align_up((size_t)(over * r + 0.999), 32);
+  // The block is capped at 256 columns (register-resident Cholesky, chol.hip).  A kept rank whose preferred block would
+  // be wider still takes the filter with the capped block while that leaves >= `min_over` of oversampling: the boundary
+  // (lambda_r against lambda_{r'+1}) is closer, so the device-side planner spends more products, but a Rayleigh-Ritz
+  // tournament over 256 columns instead of N = 480 / 512 is still the shorter chain (ResNet-18 layer4: r = 210 / 220).
+  double min_over = 1.15;
+  if (const char* o = getenv("TADMM_FILTER_MIN_OVERSAMPLE")) min_over = atof(o);
+  if (rp > 256) {
+    rp = 256;
+    if ((double)rp < min_over * r) return 0;
+  }
+  if (rp * 100 > 56 * N || rp <= r) return 0;
   return rp;
 }
 

@@ -80,10 +80,10 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
   const int K = d.K;
   // Accumulation.  One fp32 MFMA accumulator over all of K rounds K times; when every product is equal (constant or
   // rank-1 weights: all partial sums round the same way) the error grows like K eps instead of sqrt(K) eps and reached
-  // 1.3e-5 of ||W|| at K = 4608 -- above the 1e-5 parity bar.  The K range is therefore accumulated in chunks of 2 BK = 32
-  // (16 MFMAs) into two alternating accumulators, and each finished chunk is added to an fp64 total on the vector ALU
-  // (a convert and an add per entry) while the matrix pipe works on the other accumulator: error <= 32 eps inside a
-  // chunk (~1e-6 relative in the all-equal worst case), nothing from the sum of the chunks, whatever K.
+  // 1.3e-5 of ||W|| at K = 4608 -- above the 1e-5 parity bar.  The K range is therefore accumulated in chunks of 4 BK = 64
+  // (32 MFMAs) into two alternating accumulators, and each finished chunk is added to an fp64 total on the vector ALU
+  // (a convert and an add per entry) while the matrix pipe works on the other accumulator: error <= 64 eps inside a
+  // chunk (~2e-6 relative in the all-equal worst case), nothing from the sum of the chunks, whatever K.
   typedef double double16_t __attribute__((ext_vector_type(16)));
   const float16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float16_t acc0 = zero16, acc1 = zero16;
@@ -113,16 +113,23 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
   };
-  for (int k0 = 0; k0 < K; k0 += 4 * BK) {
-    step(k0, acc0);
-    fold(acc1);                        // the previous chunk (its MFMAs retired long ago): overlaps with this chunk's
-    __syncthreads();
-    if (k0 + BK < K) { step(k0 + BK, acc0); __syncthreads(); }
-    if (k0 + 2 * BK < K) {
-      step(k0 + 2 * BK, kComp ? acc1 : acc0);
-      fold(acc0);
-      __syncthreads();
-      if (k0 + 3 * BK < K) { step(k0 + 3 * BK, kComp ? acc1 : acc0); __syncthreads(); }
+  // chunks of 4 BK = 64: acc0 takes the even chunks, acc1 the odd ones (plain mode: everything into acc0)
+  for (int k0 = 0; k0 < K; k0 += 8 * BK) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k0 + u * BK < K) {
+        step(k0 + u * BK, acc0);
+        if (u == 0) fold(acc1);      // the previous chunk (its MFMAs retired long ago): overlaps with this chunk's
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int u = 4; u < 8; ++u) {
+      if (k0 + u * BK < K) {
+        step(k0 + u * BK, kComp ? acc1 : acc0);
+        if (u == 4) fold(acc0);
+        __syncthreads();
+      }
     }
   }
   fold(acc0);

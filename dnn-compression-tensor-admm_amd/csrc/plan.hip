@@ -758,17 +758,30 @@ static bool lane_split(tadmm_handle h, int n, const tadmm_layer_desc* descs, std
   double thr = 0.6;
   if (const char* e = getenv("TADMM_LANE_THRESHOLD")) thr = atof(e);
   std::vector<double> lat(n, 0.0);
+  std::vector<int> nfilt(n, 0);
   double lmax = 0.0;
   for (int l = 0; l < n; ++l) {
     LayerGeom g;
     if (build_geom(h, descs[l], g)) return false;
-    for (const StepGeom& st : g.steps) if (!st.skip) lat[l] += step_latency_us(st.N, st.r);
+    for (const StepGeom& st : g.steps)
+      if (!st.skip) {
+        lat[l] += step_latency_us(st.N, st.r);
+        nfilt[l] += filter_block_size(st.N, st.r) > 0 ? 1 : 0;
+      }
     lmax = std::max(lmax, lat[l]);
   }
   int n0 = 0;
   double t1 = 0.0;
+  // A level runs its filter stages BEFORE the Jacobi group that holds the Rayleigh-Ritz problems AND the level's full
+  // solves (single_run), so a long chain of full solves sharing a plan with filtered chains waits for their filters at
+  // every level (ResNet-18: layer4.0.conv1, N = 480 keep 236, beside the three filtered layer4 chains).  When the long
+  // chains are of both kinds, the unfiltered ones go to lane 1: their tournaments then run beside the filter stages.
+  bool long_filt = false, long_full = false;
+  for (int l = 0; l < n; ++l)
+    if (lat[l] >= thr * lmax) { if (nfilt[l] > 0) long_filt = true; else long_full = true; }
+  const bool mixed = long_filt && long_full;
   for (int l = 0; l < n; ++l) {
-    lane_of[l] = lat[l] >= thr * lmax ? 0 : 1;
+    lane_of[l] = (lat[l] >= thr * lmax && !(mixed && nfilt[l] == 0)) ? 0 : 1;
     if (lane_of[l] == 0) ++n0; else t1 += lat[l];
   }
   if (n0 == 0 || n - n0 < 2 || t1 < 0.2 * lmax) {

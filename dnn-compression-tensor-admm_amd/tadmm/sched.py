@@ -93,7 +93,11 @@ def filter_block_size(N: int, r: int) -> int:
     if N < 192 or r < 16:
         return 0
     rp = -(-int(1.55 * r + 0.999) // 32) * 32
-    if rp > 256 or rp * 100 > 56 * N or rp <= r:
+    if rp > 256:                      # capped block: still filtered while it keeps >= 1.15 of oversampling
+        rp = 256
+        if rp < 1.15 * r:
+            return 0
+    if rp * 100 > 56 * N or rp <= r:
         return 0
     return rp
 
