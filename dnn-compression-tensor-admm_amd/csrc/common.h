@@ -284,6 +284,20 @@ struct FiltParams {
   double sin_tol;             // acceptance threshold of the verification
   double log_precise;         // log-amplification the fp64 stages must contribute once fp32-accuracy stages were used
 };
+// complement route (complement.hip): a step that discards few vectors is solved for the discarded subspace of G' = cI - G
+struct CompDesc {
+  FiltState* st;                             // the filtered problem's state: `bad` gates everything
+  const double* G; double* Gc;               // [Npad][ldg] Gram image and its reflection (the filter's operand)
+  int32_t N, Npad, ldg;
+  double* cshift;                            // [1] the shift c
+  const double* UT; int32_t ldy, k;          // Ritz vectors of G' as rows [align32(k)][ldy]: the k trailing eigenvectors of G
+  double* Cimg; int32_t r;                   // [r][ldy] the kept basis, rows = vectors
+  float* out_a; int32_t ldo;                 // EigDesc mode-0 output: out_a[i * R + c]
+  double* sigma_layer;                       // [r] singular-value slot of the plan (filled with NaN: not available)
+};
+void launch_comp_prepare(const CompDesc* descs_dev, int nprob, int npad_max, int steps, hipStream_t s);
+void launch_comp_form(const CompDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);   // local = 4 rows of C^T
+void launch_comp_emit(const CompDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);   // local = 4 vectors
 void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s);
 void launch_filt_guard(const FiltProb* probs_dev, int nprob, int npad_max, int rp_max, int steps, hipStream_t s);
 // stage_fast: bit 0 = this stage's products run in dgemm3 (fp32 accuracy), bit 1 = the stage-0 product did

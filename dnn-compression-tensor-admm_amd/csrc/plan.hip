@@ -429,10 +429,23 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       e.evec_out = nullptr;
       e.sblk = (double*)dev(sblk_off);
       ed.push_back(e);
+      const bool zonly = (g.desc.flags & TADMM_FLAG_SKIP_ROTATIONS) && !(cores && cores[l]);
       if (const int rp = filter_block_size(st.N, st.r)) {
         FilterSpec fs;
         fs.N = st.N; fs.Npad = st.Npad; fs.ldg = st.ld; fs.r = st.r; fs.rp = rp;
         fs.G = e.XT; fs.mode = e.mode; fs.ldo = e.ldo; fs.out_a = e.out_a; fs.out_b = e.out_b; fs.sigma = e.sigma;
+        fs.skip_slot = (int32_t*)dev(sp.skip_off) + p;
+        fspecs.push_back(fs);
+        sp.filt_of.push_back(p);
+      } else if (const int rpc = complement_block_size(st.N, st.r, st.trans, zonly)) {
+        // complement route (complement.hip): the filter runs on the reflected image G' for the N - r DISCARDED vectors
+        FilterSpec fs;
+        const int kdis = st.N - st.r;
+        fs.N = st.N; fs.Npad = st.Npad; fs.ldg = st.ld; fs.r = kdis; fs.rp = rpc;
+        fs.G = (const double*)dev(ar.take((size_t)st.Npad * st.ld * 8));
+        fs.g_orig = e.XT; fs.comp_r = st.r; fs.sigma_layer = e.sigma;
+        fs.mode = 4; fs.ldo = e.ldo; fs.out_a = e.out_a; fs.out_b = nullptr;
+        fs.sigma = (double*)dev(ar.take((size_t)align_up(kdis, 32) * 8));      // (Ritz values of G': scratch)
         fs.skip_slot = (int32_t*)dev(sp.skip_off) + p;
         fspecs.push_back(fs);
         sp.filt_of.push_back(p);
@@ -741,7 +754,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
 
 // ---- lanes: split rule, creation, the worker of lane 1 ----
 // modelled latency (us) of one eigen-problem alone on the device; mirrors tadmm/sched.py problem_latency_us
-static double step_latency_us(int N, int r) {
+static double step_latency_us_full_or_filtered(int N, int r) {
   const int npad = (int)align_up(N, 32);
   if (npad <= 64) return 100.0;
   const int rp = filter_block_size(N, r);
@@ -765,8 +778,10 @@ static bool lane_split(tadmm_handle h, int n, const tadmm_layer_desc* descs, std
     if (build_geom(h, descs[l], g)) return false;
     for (const StepGeom& st : g.steps)
       if (!st.skip) {
-        lat[l] += step_latency_us(st.N, st.r);
-        nfilt[l] += filter_block_size(st.N, st.r) > 0 ? 1 : 0;
+        const bool zonly = (descs[l].flags & TADMM_FLAG_SKIP_ROTATIONS) != 0;
+        const bool comp = !filter_block_size(st.N, st.r) && complement_block_size(st.N, st.r, st.trans, zonly) > 0;
+        lat[l] += comp ? 1500.0 : step_latency_us_full_or_filtered(st.N, st.r);
+        nfilt[l] += (filter_block_size(st.N, st.r) > 0 || comp) ? 1 : 0;
       }
     lmax = std::max(lmax, lat[l]);
   }
@@ -780,10 +795,43 @@ static bool lane_split(tadmm_handle h, int n, const tadmm_layer_desc* descs, std
   for (int l = 0; l < n; ++l)
     if (lat[l] >= thr * lmax) { if (nfilt[l] > 0) long_filt = true; else long_full = true; }
   const bool mixed = long_filt && long_full;
+  // Long chains of FULL solves beside filtered / complement chains of any length (DeiT-small: the N = 384 solves of qkv /
+  // fc1 beside the complement route of proj / fc2): a filtered chain is a few hundred SMALL dependent launches, a full
+  // tournament a few hundred launches that fill the chip.  The small ones go to lane 0 -- the high-priority stream --
+  // where each of them finds CUs at once and delays the big launches by next to nothing; as the low-priority lane they
+  // waited for a whole tick launch every time (measured: 11.3 ms instead of 10.0 ms without the route).
+  bool any_filt = false;
+  for (int l = 0; l < n; ++l) any_filt = any_filt || nfilt[l] > 0;
+  const bool by_kind = long_full && any_filt && !long_filt;
   for (int l = 0; l < n; ++l) {
-    lane_of[l] = (lat[l] >= thr * lmax && !(mixed && nfilt[l] == 0)) ? 0 : 1;
-    if (lane_of[l] == 0) ++n0; else t1 += lat[l];
+    if (by_kind) lane_of[l] = nfilt[l] > 0 ? 0 : 1;
+    else lane_of[l] = (lat[l] >= thr * lmax && !(mixed && nfilt[l] == 0)) ? 0 : 1;
   }
+  if (by_kind) {
+    // a tournament launch of lane 1 holds Npad / 32 workgroups per problem, one per CU (128 KiB of LDS each): one more
+    // than the device has CUs and every tick of the lane takes two rounds.  The excess (shortest chains first) rides in
+    // lane 0 behind that lane's filter stages.
+    int ncu = 256;
+    if (h) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, h->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+    std::vector<int> wgs(n, 0);
+    long total = 0;
+    for (int l = 0; l < n; ++l) {
+      if (lane_of[l] != 1) continue;
+      LayerGeom g;
+      if (build_geom(h, descs[l], g)) return false;
+      for (const StepGeom& st : g.steps) if (!st.skip) wgs[l] = std::max(wgs[l], st.Npad / 32);
+      total += wgs[l];
+    }
+    std::vector<int> order;
+    for (int l = 0; l < n; ++l) if (lane_of[l] == 1 && wgs[l] >= 4) order.push_back(l);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lat[a] < lat[b]; });
+    for (int l : order) {
+      if (total <= ncu) break;
+      lane_of[l] = 0;
+      total -= wgs[l];
+    }
+  }
+  for (int l = 0; l < n; ++l) { if (lane_of[l] == 0) ++n0; else t1 += lat[l]; }
   if (n0 == 0 || n - n0 < 2 || t1 < 0.2 * lmax) {
     // no short side to hide behind the long chains.  A big table of like layers (DeiT-small: 48 layers, every chain
     // within 0.6 of the longest) still gains from two half tables on two streams -- one lane's GEMM phases fill the gaps

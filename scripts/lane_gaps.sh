@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/lane_gaps
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-per-layer --no-forward > $OUT/bench.json 2> $OUT/err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $R/bench.py --config ${CFG:-resnet50_tt} --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-per-layer --no-forward > $OUT/bench.json 2> $OUT/err
 python3 - <<PY
 import csv, glob, collections, re
 f = glob.glob('$OUT/t/**/*kernel_trace.csv', recursive=True)[0]

@@ -208,3 +208,37 @@ def test_ten_class_head_trains(dev):
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
         with torch.no_grad():                      # inference keeps the one-launch path (no gradient rows involved)
             np.testing.assert_allclose(layer(x0).cpu().numpy(), yr.cpu().numpy(), atol=2e-5)
+
+
+def test_complement_route_is_opt_in_and_matches_the_oracle(dev, monkeypatch):
+    """The complement route (csrc/complement.hip: filter the DISCARDED subspace of G' = cI - G, keep its orthogonal
+    complement) on a DeiT-small `proj` layer (288 x 384 unfolding, keep 256 of 288): opt-in, Z equal to the oracle and to
+    the default (full solve) path."""
+    from oracle import tt_oracle as O
+    from tadmm import ops
+    from tadmm._cabi import KIND_TT_LINEAR
+    rng = np.random.default_rng(21)
+    tts, ranks = (24, 16, 16, 24), (1, 18, 256, 18, 1)
+    w = (rng.standard_normal((384, 384)) * np.sqrt(2.0 / 384)).astype(np.float32)
+    ref = O.prune_linear_rank_tt(w, list(tts), list(ranks))
+
+    def run(flag):
+        if flag is None:
+            monkeypatch.delenv("TADMM_COMPLEMENT", raising=False)
+        else:
+            monkeypatch.setenv("TADMM_COMPLEMENT", flag)
+        t = torch.from_numpy(w).to(dev)
+        L = dict(kind=KIND_TT_LINEAR, W=t, U=torch.zeros_like(t), Z=torch.empty_like(t), tt_shapes=list(tts), ranks=list(ranks))
+        plan = ops.ProjectionPlan([L])
+        plan.run(update_u=False, use_u=False)
+        st = plan.filter_stats()
+        plan.close()
+        return L["Z"].cpu().numpy(), st
+
+    z0, st0 = run(None)
+    assert st0["eligible"] == 0                       # default: the full Jacobi solve
+    z1, st1 = run("1")
+    assert st1["eligible"] == 1, st1                  # opt-in: the N = 288 step takes the complement route
+    for z in (z0, z1):
+        assert np.linalg.norm(z - ref) <= 1e-5 * np.linalg.norm(ref)
+    assert np.linalg.norm(z1 - z0) <= 2e-6 * np.linalg.norm(z0)
