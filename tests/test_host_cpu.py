@@ -368,3 +368,71 @@ def test_every_table_with_known_shapes_sizes_a_plan():
             assert rc == 0 and size.value > 0, (key, lib.tadmm_last_error(h).decode())
     assert covered == 36, covered
     lib.tadmm_destroy(h)
+
+
+# ---------------------------------------------------------------- round 3: host logic added this round
+def test_filter_block_is_capped_not_refused():
+    """csrc/filter_host.h and its mirror in sched.py: a preferred block wider than 256 columns is capped while it keeps at
+    least 1.15 of oversampling (ResNet-18 layer4: r = 210 / 220), refused below that (r = 236) and by the 0.56 N rule."""
+    from tadmm import sched
+    assert sched.filter_block_size(512, 105) == 192          # ResNet-50 layer4: unchanged
+    assert sched.filter_block_size(512, 130) == 224
+    assert sched.filter_block_size(480, 210) == 256 and sched.filter_block_size(512, 220) == 256
+    assert sched.filter_block_size(480, 236) == 0             # 256 / 236 = 1.08
+    assert sched.filter_block_size(384, 256) == 0 and sched.filter_block_size(288, 256) == 0     # DeiT-small: nothing
+    assert sched.filter_block_size(240, 138) == 0             # 0.56 N rule
+
+
+def test_launch_memo_is_a_small_lru():
+    from tadmm import ops
+    m = ops._LruMemo()
+    for i in range(ops._LruMemo.CAP + 40):
+        m.store(("k", i), i)
+    assert len(m) == ops._LruMemo.CAP
+    assert m.lookup(("k", 0)) is None and m.lookup(("k", 50)) == 50
+    m.store(("k", "new"), 1)                                   # ("k", 50) was just used: it survives, the oldest goes
+    assert m.lookup(("k", 50)) == 50 and m.lookup(("k", 40)) is None
+
+
+def test_inference_caches_are_dropped_by_mode_switches_and_loads():
+    import torch
+    from tadmm import functional as HF
+
+    class L(HF.InferenceCacheMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(3))
+
+    layer = L()
+    for trigger in (lambda: layer.eval(), lambda: layer.train(), lambda: layer.double(), lambda: layer.load_state_dict(layer.state_dict()),
+                    lambda: layer.invalidate_caches()):
+        layer.__dict__["_chain_cache"] = {"key": 1}
+        layer.__dict__["_plane_cache"] = {"x": 2}
+        trigger()
+        assert "_chain_cache" not in layer.__dict__ and "_plane_cache" not in layer.__dict__
+    p = layer.w
+    k0 = HF.param_key(p)
+    p.data = torch.ones(3, dtype=p.dtype)                      # new storage, same version counter
+    assert HF.param_key(p) != k0
+
+
+def test_pmc_traffic_is_only_stamped_on_a_matching_launch_count():
+    import bench
+    pm = {"k": {"hbm_bytes_per_launch_corrected": 123.0, "launches_per_step": 100.0}, "old": {"hbm_bytes_per_launch_corrected": 5.0}}
+    meta = {"file": "profiles/x.json", "commit": "abc1234"}
+    t, src = bench.pmc_traffic_for(pm, meta, "k", 104.0, 1)
+    assert t == 123.0 and "abc1234" in src
+    t, src = bench.pmc_traffic_for(pm, meta, "k", 130.0, 1)
+    assert t is None and "dropped" in src
+    assert bench.pmc_traffic_for(pm, meta, "old", 100.0, 1)[0] is None         # a pass without provenance
+    assert bench.pmc_traffic_for(pm, meta, "k", 100.0, 2)[0] is None           # multi-GPU: no PMC pass
+
+
+def test_tucker_flop_model():
+    import bench
+    f = bench.tucker_flops((64, 64, 3, 3), [25, 23], 3)
+    assert f["numel"] == 36864 and f["eig"] == 8.0 * 64 ** 3 * (2 + 2 * 3)
+    hosvd = 2.0 * 576 * 64 * 64 * 2
+    per = 2.0 * 64 * 9 * 64 * 23 + 2.0 * (9 * 23) * 64 * 64 + 2.0 * 64 * 9 * 64 * 25 + 2.0 * (9 * 25) * 64 * 64 + 2.0 * 25 * 9 * 64 * 23
+    final = 2.0 * 25 * 9 * 23 * 64 + 2.0 * 64 * 25 * 9 * 64
+    assert abs(f["mfma"] - (hosvd + 3 * per + final)) < 1.0
