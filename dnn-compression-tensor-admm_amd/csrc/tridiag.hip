@@ -174,29 +174,27 @@ __device__ __forceinline__ void eig_small_direct_body(const EigDesc& d, int p, d
       // every wave forms the reflector redundantly (lane l <-> row l)
       const double x = (lane > k) ? xs[lane] : 0.0;
       const double alpha = xs[k + 1];
+      // the entries of the column this thread's tile rows / columns will need, requested together with the above: the
+      // reflector's entries are then formed from registers (no LDS round trip of v behind the reduction)
+      const double2_t xr0 = *reinterpret_cast<const double2_t*>(&xs[4 * R]), xr1 = *reinterpret_cast<const double2_t*>(&xs[4 * R + 2]);
+      const double2_t xc0 = *reinterpret_cast<const double2_t*>(&xs[4 * Cc]), xc1 = *reinterpret_cast<const double2_t*>(&xs[4 * Cc + 2]);
       const double xn2 = wave_sum((lane > k + 1) ? x * x : 0.0);
-      double tau = 0.0, beta = alpha, v = (lane == k + 1) ? 1.0 : 0.0;
+      double tau = 0.0, beta = alpha, sc = 0.0;
       if (xn2 > 0.0) {                                // uniform
         beta = -copysign(fast_sqrt(fma(alpha, alpha, xn2)), alpha);
         tau = (beta - alpha) * fast_rcp(beta);
-        const double sc = fast_rcp(alpha - beta);
-        if (lane > k + 1) v = x * sc;
+        sc = fast_rcp(alpha - beta);
       }
-      vs[lane] = v;
+      auto vof = [&](int i, double xi) { return i == k + 1 ? 1.0 : (i > k + 1 ? xi * sc : 0.0); };
       if (wave == 0) {
-        Hv[k][lane] = v;
+        Hv[k][lane] = vof(lane, x);
         if (lane == 0) { ee[k] = beta; tauv[k] = tau; }
       }
-      wave_fence();
       TSUB(1);
       if (tau != 0.0) {                               // uniform
         double vr[4], vc[4], pr[4];
-        {
-          const double2_t r0 = *reinterpret_cast<const double2_t*>(&vs[4 * R]), r1 = *reinterpret_cast<const double2_t*>(&vs[4 * R + 2]);
-          const double2_t c0 = *reinterpret_cast<const double2_t*>(&vs[4 * Cc]), c1 = *reinterpret_cast<const double2_t*>(&vs[4 * Cc + 2]);
-          vr[0] = r0.x; vr[1] = r0.y; vr[2] = r1.x; vr[3] = r1.y;
-          vc[0] = c0.x; vc[1] = c0.y; vc[2] = c1.x; vc[3] = c1.y;
-        }
+        vr[0] = vof(4 * R, xr0.x); vr[1] = vof(4 * R + 1, xr0.y); vr[2] = vof(4 * R + 2, xr1.x); vr[3] = vof(4 * R + 3, xr1.y);
+        vc[0] = vof(4 * Cc, xc0.x); vc[1] = vof(4 * Cc + 1, xc0.y); vc[2] = vof(4 * Cc + 2, xc1.x); vc[3] = vof(4 * Cc + 3, xc1.y);
         double t4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) t4[r] = (a[r][0] * vc[0] + a[r][1] * vc[1]) + (a[r][2] * vc[2] + a[r][3] * vc[3]);
