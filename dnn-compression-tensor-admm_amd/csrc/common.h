@@ -259,6 +259,8 @@ struct FiltState {
   double b, lr, l1;           // bounds used by the last stage (diagnostics)
   double crit;                // verification figure: bound on ||sin Theta||_F of the accepted subspace
   double guard;               // power-iteration estimate of the largest eigenvalue OUTSIDE the block (filt_guard_kernel)
+  double mom[64 * 5];         // filt_moments_kernel: per-workgroup partials of ||G||_F^2, tr G, ||GQ||_F^2, ||H||_F^2, tr H
+  int32_t mom_on;             // 1 when the partials above belong to this run
 };
 struct FiltProb {
   FiltState* st;
@@ -276,6 +278,7 @@ struct FiltProb {
   int32_t* skip_slot;                       // word of the eig group's skip array that belongs to this problem
   int32_t* fb_skip;                         // word of the fallback group's skip array: 1 = filtered result accepted
   const double* G; int32_t ldg;             // the problem's matrix [Npad][ldg] (guard: products with single vectors)
+  const double* H; int32_t ldh;             // Rayleigh-Ritz image H = Q^T G Q [rp][ldh] (moments guard; overwritten by the solve)
 };
 struct FiltParams {
   int32_t max_degree;         // recurrence steps per stage (D)
@@ -300,6 +303,7 @@ void launch_comp_form(const CompDesc* descs_dev, const BlockRef* map_dev, int nb
 void launch_comp_emit(const CompDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);   // local = 4 vectors
 void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nblocks, int nprob, hipStream_t s);
 void launch_filt_guard(const FiltProb* probs_dev, int nprob, int npad_max, int rp_max, int steps, hipStream_t s);
+void launch_filt_moments(const FiltProb* probs_dev, int nprob, hipStream_t s);
 // stage_fast: bit 0 = this stage's products run in dgemm3 (fp32 accuracy), bit 1 = the stage-0 product did
 void launch_filt_plan(const FiltProb* probs_dev, int nprob, FiltParams prm, int last_stage, int stage_fast, int* verdict_pinned,
                       hipStream_t s);

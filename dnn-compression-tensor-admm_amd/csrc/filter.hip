@@ -23,6 +23,9 @@
 
 namespace tadmm {
 
+typedef double double2v_t __attribute__((ext_vector_type(2)));
+constexpr int kMomParts = 64;      // workgroups per problem of the moments guard
+
 __device__ __forceinline__ double hash_unit(uint32_t a, uint32_t b) {
   // splitmix-style integer hash -> uniform in (-1, 1); fixed function of (problem, element): deterministic runs
   uint64_t x = ((uint64_t)a << 32) ^ (uint64_t)b;
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void filt_init_kernel(const FiltProb* __restri
     st->base = 0; st->res = 1; st->nsteps = 0; st->active = 1; st->alive = 1; st->bad = 0; st->stage = 0;
     st->products = 2;       // stage-0 product + the product in front of the Rayleigh-Ritz projection
     st->products_fast = 0; st->precise_stages = 0; st->logamp_precise = 0.0;
-    st->logamp = 0.0; st->crit = 0.0; st->b = st->lr = st->l1 = 0.0; st->guard = 0.0;
+    st->logamp = 0.0; st->crit = 0.0; st->b = st->lr = st->l1 = 0.0; st->guard = 0.0; st->mom_on = 0;
     *p.skip_slot = 0;
     *p.fb_skip = 0;
   }
@@ -198,12 +201,77 @@ __global__ __launch_bounds__(256) void filt_verdict_kernel(const FiltProb* __res
     st->crit = crit;
     // (guard: filt_guard_kernel; 0 when the guard did not run.  NaN compares false -> rejected by the negation)
     const double th_r = p.theta[p.r - 1];
-    const bool guard_ok = !(st->guard > th_r * (1.0 + 1e-9)) && st->guard == st->guard;
+    bool guard_ok = !(st->guard > th_r * (1.0 + 1e-9)) && st->guard == st->guard;
+    if (st->mom_on) {                        // moments guard (filt_moments_kernel): ||D||_F^2 / tr D <= lambda_max(D) must stay below theta_r
+      double m[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int w = 0; w < kMomParts; ++w)
+        for (int q = 0; q < 5; ++q) m[q] += st->mom[w * 5 + q];
+      const double trd = m[1] - m[4], d2 = m[0] - 2.0 * m[2] + m[3];
+      const double bound = trd > 0.0 ? d2 / trd : 0.0;
+      if (bound > th_r * (1.0 + 1e-6) || bound != bound) guard_ok = false;
+      st->guard = fmax(st->guard, bound);
+    }
     const bool ok = crit <= prm.sin_tol && guard_ok;     // false for NaN
     if (!ok) { st->bad = 1; st->alive = 0; }
     *p.fb_skip = ok ? 1 : 0;
     verdict[1 + blockIdx.x] = ok ? 1 : 0;
   }
+}
+
+// Moments guard: a lower bound of the largest eigenvalue the block does NOT contain, from quantities that are lying around.
+// With P = I - Q Q^T (Q orthonormal), T = G Q and H = Q^T G Q the deflated operator D = P G P has
+//      tr D = tr G - tr H,        ||D||_F^2 = ||G||_F^2 - 2 ||T||_F^2 + ||H||_F^2,
+// and ||D||_F^2 / tr D is a weighted mean of its (non-negative) eigenvalues, hence <= lambda_max(D): a healthy block leaves
+// only eigenvalues below the r-th Ritz value out there and the ratio stays below it whatever the spectrum; an eigenvector
+// that dominates what is left and that the block never acquired pushes it above.  One pass over G, T and H by 64
+// workgroups per problem, in line behind the product that forms H (~3 us); partials are summed in a fixed order by the
+// verdict kernel.  Weaker than power steps when the missed eigenvalue is one among many of similar size -- neither catches
+// that within a few steps -- and two orders of magnitude cheaper: the power-step guard below costs 0.35 ms of a 6.8 ms
+// iteration even on a side stream (measured in separate processes on one box: 6.84 / 7.19 / 7.28 ms for off / side
+// stream / in line), so it is the opt-in (TADMM_FILTER_GUARD=n) and this one the default.
+__global__ __launch_bounds__(256) void filt_moments_kernel(const FiltProb* __restrict__ probs) {
+  __shared__ double red[5][4];
+  const FiltProb p = probs[blockIdx.x];
+  FiltState* st = p.st;
+  if (st->bad) return;
+  const int part = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tb = st->base + 1;
+  tb -= tb >= 3 ? 3 : 0;
+  // the three images are zero in their padding, so the squared sums run over the flat arrays: each workgroup one
+  // contiguous slice, eight 16-byte loads in flight per thread
+  auto sumsq = [&](const double* __restrict__ a, int64_t total) {
+    const int64_t per = ((total / kMomParts + 511) / 512) * 512;          // multiple of 2 * 256
+    const int64_t lo = (int64_t)part * per, hi = lo + per < total ? lo + per : total;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int64_t i = lo + 2 * tid; i < hi; i += 2048) {
+      double2v_t v0 = {0, 0}, v1 = {0, 0}, v2 = {0, 0}, v3 = {0, 0};
+      v0 = *reinterpret_cast<const double2v_t*>(a + i);
+      if (i + 512 < hi) v1 = *reinterpret_cast<const double2v_t*>(a + i + 512);
+      if (i + 1024 < hi) v2 = *reinterpret_cast<const double2v_t*>(a + i + 1024);
+      if (i + 1536 < hi) v3 = *reinterpret_cast<const double2v_t*>(a + i + 1536);
+      s0 += v0.x * v0.x + v0.y * v0.y; s1 += v1.x * v1.x + v1.y * v1.y;
+      s2 += v2.x * v2.x + v2.y * v2.y; s3 += v3.x * v3.x + v3.y * v3.y;
+    }
+    return (s0 + s1) + (s2 + s3);
+  };
+  const double g2 = sumsq(p.G, (int64_t)p.Npad * p.ldg);
+  const double t2 = sumsq(p.ring[tb], (int64_t)p.rp * p.ldy);
+  const double h2 = sumsq(p.H, (int64_t)p.rp * p.ldh);
+  double tg = 0.0, th = 0.0;
+  if (part == 0) {
+    for (int i = tid; i < p.N; i += 256) tg += p.G[(int64_t)i * p.ldg + i];
+    for (int j = tid; j < p.rp; j += 256) th += p.H[(int64_t)j * p.ldh + j];
+  }
+  double v[5] = {g2, tg, t2, h2, th};
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 64);
+    if (lane == 0) red[q][wave] = v[q];
+  }
+  __syncthreads();
+  if (tid < 5) st->mom[part * 5 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+  if (part == 0 && tid == 0) st->mom_on = 1;
 }
 
 // Independent guard of the filtered solve.  The residual-based acceptance test bounds the error of the Ritz pairs it is
@@ -384,6 +452,10 @@ void launch_filt_init(const FiltProb* probs_dev, const BlockRef* map_dev, int nb
   int zero_col = -1;
   if (const char* e = getenv("TADMM_FILTER_TEST_ZERO_COL")) zero_col = atoi(e);
   hipLaunchKernelGGL(filt_init_kernel, dim3(nblocks), dim3(256), 0, s, probs_dev, map_dev, zero_col);
+}
+void launch_filt_moments(const FiltProb* probs_dev, int nprob, hipStream_t s) {
+  if (nprob <= 0) return;
+  hipLaunchKernelGGL(filt_moments_kernel, dim3(nprob, kMomParts), dim3(256), 0, s, probs_dev);
 }
 void launch_filt_guard(const FiltProb* probs_dev, int nprob, int npad_max, int rp_max, int steps, hipStream_t s) {
   if (nprob <= 0 || steps <= 0) return;

@@ -31,10 +31,16 @@ static inline int filter_block_size(int N, int r) {
   return rp;
 }
 
-// power steps of the independent guard (filt_guard_kernel); TADMM_FILTER_GUARD=0 switches it off (A/B, tests)
+// Guards of the filtered solve (filter.hip).  TADMM_FILTER_GUARD unset: the moments guard (in line, ~3 us); = n > 0: the
+// moments guard AND n power steps on the deflated operator (side stream; 0.35 ms of the ResNet-50 iteration); = 0: none
+// (A/B measurements, tests).
 static inline int filter_guard_steps() {
   if (const char* e = getenv("TADMM_FILTER_GUARD")) return std::max(0, std::min(16, atoi(e)));
-  return 3;
+  return 0;
+}
+static inline bool filter_moments_on() {
+  const char* e = getenv("TADMM_FILTER_GUARD");
+  return !(e && atoi(e) == 0);
 }
 
 static inline int filter_tile_n() {
@@ -225,6 +231,7 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     p.mode = sp.mode; p.ldo = sp.ldo; p.out_a = sp.out_a; p.out_b = sp.out_b;
     p.skip_slot = sp.skip_slot; p.fb_skip = sp.fb_skip;
     p.G = sp.G; p.ldg = sp.ldg;
+    p.H = (const double*)dev(xth_off[i]); p.ldh = ldh;
     fg.npad_max = std::max(fg.npad_max, Npad); fg.rp_max = std::max(fg.rp_max, rp);
     auto base_desc = [&](int M, int N_, int K) {
       DgemmDesc g;
@@ -533,7 +540,8 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   cholqr(fg.gramB, fg.cholB_off);        // second pass: orthonormal to rounding
   launch_filt_flags(probs, fg.nf, s);
   fg.guard_forked = false;
-  if (filter_guard_steps() > 0) {            // the guard reads the final block Q = ring[base] and G only: fork it here
+  if (filter_guard_steps() > 0 && !(getenv("TADMM_GUARD_INLINE") && atoi(getenv("TADMM_GUARD_INLINE")))) {
+    // the guard reads the final block Q = ring[base] and G only: fork it here
     if (!fg.side) fg.side = std::make_shared<GuardSide>();
     if (fg.side->ok && hipEventRecord(fg.side->fork, s) == hipSuccess &&
         hipStreamWaitEvent(fg.side->st, fg.side->fork, 0) == hipSuccess) {
@@ -543,6 +551,7 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   }
   gemm(fg.tfinal);
   gemm(fg.hform);
+  if (filter_moments_on()) launch_filt_moments(probs, fg.nf, s);     // H is about to be overwritten by its own eigen-solve
   if (debug) fprintf(stderr, "[tadmm] filter: %d problems, %d stages of <= %d steps\n", fg.nf, stages, fg.max_degree);
   return TADMM_OK;
 }

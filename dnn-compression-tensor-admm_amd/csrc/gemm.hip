@@ -81,24 +81,19 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
   // Accumulation.  One fp32 MFMA accumulator over all of K rounds K times; when every product is equal (constant or
   // rank-1 weights: all partial sums round the same way) the error grows like K eps instead of sqrt(K) eps and reached
   // 1.3e-5 of ||W|| at K = 4608 -- above the 1e-5 parity bar.  The K range is therefore accumulated in chunks of 4 BK = 64
-  // (32 MFMAs) into two alternating accumulators, and each finished chunk is added to an fp64 total on the vector ALU
-  // (a convert and an add per entry) while the matrix pipe works on the other accumulator: error <= 64 eps inside a
-  // chunk (~2e-6 relative in the all-equal worst case), nothing from the sum of the chunks, whatever K.
-  typedef double double16_t __attribute__((ext_vector_type(16)));
+  // (32 MFMAs); a finished chunk is added to a second set of 16 registers on the vector ALU and the accumulator restarts
+  // from zero: the rounding bias of a chunk is at most 64 eps / 2 of ITS sum, that of the K / 64 additions of chunks the
+  // same again -- two orders of magnitude below the single-accumulator figure at K = 4608 (measured: <= 4e-7).  A first
+  // version with two alternating accumulators and an fp64 total cost 25 % of the kernel in-plan (32 more live
+  // registers); this one waits once per chunk for the last MFMA (~3 %).
   const float16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float16_t acc0 = zero16, acc1 = zero16;
-  double16_t tot = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  auto fold = [&](float16_t& a) {
-    if (!kComp) return;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) tot[e] += (double)a[e];
-    a = zero16;
-  };
+  float16_t acc0 = zero16, tot = zero16;
 
   Frag4 fa = load_tile4(d.A, d.a_rs, d.a_cs, a_k, m0, d.M, 0, K, tid);
   Frag4 fb = load_tile4(d.B, d.b_cs, d.b_rs, b_k, n0, d.N, 0, K, tid);
   const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kq = lane >> 5;
-  auto step = [&](int k0, float16_t& acc) {
+  int chunk = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
     store_tile4(As, LDA, a_k, fa, tid);
     store_tile4(Bs, LDB, b_k, fb, tid);
     __syncthreads();
@@ -110,33 +105,19 @@ __device__ __forceinline__ void gemm_tile(const GemmDesc& d, int local, float* _
     for (int kk = 0; kk < BK; kk += 2) {
       const float a = As[(kk + kq) * LDA + ai];
       const float b = Bs[(kk + kq) * LDB + bj];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
     }
-  };
-  // chunks of 4 BK = 64: acc0 takes the even chunks, acc1 the odd ones (plain mode: everything into acc0)
-  for (int k0 = 0; k0 < K; k0 += 8 * BK) {
+    if (kComp && ++chunk == 4) {
+      chunk = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (k0 + u * BK < K) {
-        step(k0 + u * BK, acc0);
-        if (u == 0) fold(acc1);      // the previous chunk (its MFMAs retired long ago): overlaps with this chunk's
-        __syncthreads();
-      }
+      for (int e = 0; e < 16; ++e) tot[e] += acc0[e];
+      acc0 = zero16;
     }
-#pragma unroll
-    for (int u = 4; u < 8; ++u) {
-      if (k0 + u * BK < K) {
-        step(k0 + u * BK, kComp ? acc1 : acc0);
-        if (u == 4) fold(acc0);
-        __syncthreads();
-      }
-    }
+    __syncthreads();
   }
-  fold(acc0);
-  fold(acc1);
   float16_t acc;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = kComp ? (float)tot[e] : acc0[e];
+  for (int e = 0; e < 16; ++e) acc[e] = kComp ? tot[e] + acc0[e] : acc0[e];
 
   // epilogue: D row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
   const int col = n0 + wn * 32 + (lane & 31);

@@ -132,8 +132,10 @@ def test_guard_catches_an_eigenvector_the_block_never_contained(dev, monkeypatch
     never acquire: column k of the unfolding is supported on one row where every other column is zero, so e_k is an
     exact eigenvector of the Gram matrix (G[k][j] = 0 exactly), and the test hook TADMM_FILTER_TEST_ZERO_COL starts the
     block with no component along e_k -- products with G keep that component exactly zero.  Without the guard the
-    filtered solve passes its verification and returns a Z that misses the largest singular direction; the guard
-    (power steps on the deflated operator, csrc/filter.hip: filt_guard_kernel) must send the problem to the full solve."""
+    filtered solve passes its verification and returns a Z that misses the largest singular direction; either guard --
+    the default moments guard (||PGP||_F^2 / tr PGP from quantities at hand, csrc/filter.hip: filt_moments_kernel) or the
+    opt-in power steps on the deflated operator (filt_guard_kernel, TADMM_FILTER_GUARD=n) -- must send the problem to the
+    full solve."""
     from tadmm import ops
     from tadmm._cabi import KIND_TT_CONV
     rng = np.random.default_rng(11)
@@ -148,7 +150,10 @@ def test_guard_catches_an_eigenvector_the_block_never_contained(dev, monkeypatch
 
     def run(zero_col, guard):
         monkeypatch.setenv("TADMM_FILTER", "1")
-        monkeypatch.setenv("TADMM_FILTER_GUARD", guard)
+        if guard is None:
+            monkeypatch.delenv("TADMM_FILTER_GUARD", raising=False)
+        else:
+            monkeypatch.setenv("TADMM_FILTER_GUARD", guard)
         if zero_col is None:
             monkeypatch.delenv("TADMM_FILTER_TEST_ZERO_COL", raising=False)
         else:
@@ -161,15 +166,17 @@ def test_guard_catches_an_eigenvector_the_block_never_contained(dev, monkeypatch
         plan.close()
         return L["Z"].cpu().numpy(), st
 
-    z_ok, st_ok = run(None, "4")                     # healthy start block: no fallback, guard silent
-    assert st_ok["eligible"] == 1 and st_ok["fallbacks"] == 0, st_ok
-    assert np.linalg.norm(z_ok - ref) <= 1e-5 * np.linalg.norm(ref)
-    z_blind, st_blind = run(k, "0")                  # guard off: the planted failure is real and goes unnoticed
+    for guard in (None, "4"):                        # healthy start block: no fallback, both guards silent
+        z_ok, st_ok = run(None, guard)
+        assert st_ok["eligible"] == 1 and st_ok["fallbacks"] == 0, (guard, st_ok)
+        assert np.linalg.norm(z_ok - ref) <= 1e-5 * np.linalg.norm(ref)
+    z_blind, st_blind = run(k, "0")                  # guards off: the planted failure is real and goes unnoticed
     assert st_blind["fallbacks"] == 0, st_blind
     assert abs(z_blind[0, k, 0, 0]) < 1.0 and np.linalg.norm(z_blind - ref) > 0.5 * np.linalg.norm(ref)
-    z_g, st_g = run(k, "4")                          # guard on: rejected, full solve, right answer
-    assert st_g["fallbacks"] == 1, st_g
-    assert np.linalg.norm(z_g - ref) <= 1e-5 * np.linalg.norm(ref)
+    for guard in (None, "4"):                        # default (moments) / moments + power steps: rejected, full solve, right answer
+        z_g, st_g = run(k, guard)
+        assert st_g["fallbacks"] == 1, (guard, st_g)
+        assert np.linalg.norm(z_g - ref) <= 1e-5 * np.linalg.norm(ref)
 
 
 def test_filtered_cores_match_full_solve(dev, monkeypatch):
