@@ -78,6 +78,8 @@ def run(device=None, iters: int = 50):
                     kernel_ms = _time(go, iters)
                 r = _row("TTLinearM deit_small %s (%d tokens, ranks %s)" % (lname[:-7], T, lin.tt_ranks), dtype, ms, dense,
                          kernel_ms, alg, 1 if kernel_ms is not None else lin.tt_order)
+                r["path"] = ("recovered dense weight on the library GEMM (TTLinearM._dense_pays: long-K bf16 inference)"
+                             if lin._dense_pays(x, rq) else "fused chain kernel")
                 r["chain_flops_per_token"] = int(sum(2 * c.numel() * _rest(lin, i) for i, c in enumerate(lin.tt_cores)))
                 r["contracted_flops_per_token"] = int(2 * rq * (fin + fout))
                 r["dense_flops_per_token"] = int(2 * fin * fout)

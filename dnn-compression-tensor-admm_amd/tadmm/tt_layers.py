@@ -348,6 +348,12 @@ class TTLinearM(_TTLinearBase):
         # not 16-byte aligned (10 classes) trains through the per-core chain instead
         return self.out_features % align == 0 or not HF._needs_grad(x, self.bias, *self.tt_cores)
 
+    def _dense_pays(self, x, r_q: int) -> bool:
+        """bf16 inference only: the chain's flop count is at least 0.8 of the dense layer's and the reduction is long."""
+        if x.dtype != torch.bfloat16 or self.in_features < 1024:
+            return False
+        return r_q * (self.in_features + self.out_features) >= 0.8 * self.in_features * self.out_features
+
     def forward(self, x):
         """TTLinear.py:75-93.  One launch (`tadmm_ttlinear_fwd`) when the middle rank fits the fused kernel: the
         input cores are contracted into Win, the output cores into Wout, and y = Wout (Win x) + bias with the
@@ -365,8 +371,18 @@ class TTLinearM(_TTLinearBase):
                     with torch.no_grad():
                         w_in, w_out = self._factors()
                     cache.update(key=key, w=(w_in, w_out), planes=(HF.planes_of(w_in, n, pad_rows=64),
-                                                                   HF.planes_of(w_out, n, pad_cols=64)))
+                                                                   HF.planes_of(w_out, n, pad_cols=64)), dense=None)
                 w_in, w_out = cache["w"]
+                if self._dense_pays(x, w_in.shape[0]) and not HF._needs_grad(x, self.bias):
+                    # long-K bf16 layers whose chain saves (almost) no arithmetic (DeiT-small fc2: 983 k of 1 180 k flop per
+                    # token): every 64-token tile of the chain kernel pulls all of W_in through its CU, the library's dense
+                    # kernel reuses a weight tile across 256 tokens -- 0.027 vs 0.020 ms.  Inference therefore multiplies by
+                    # the recovered weight (cached with the other inference state), exactly what TTLinearR does every call
+                    # (TTLinear.py:151-160).
+                    if cache.get("dense") is None:
+                        with torch.no_grad():
+                            cache["dense"] = HF.mm(w_out, w_in).to(x.dtype).contiguous()
+                    return F.linear(x, cache["dense"], None if self.bias is None else self.bias.to(x.dtype))
                 return HF.linear_chain(x, w_in, w_out, self.bias, cache["planes"])
         if x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or self.tt_cores[0].requires_grad)):
             return self._forward_bf16(x)

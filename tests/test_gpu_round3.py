@@ -242,3 +242,31 @@ def test_complement_route_is_opt_in_and_matches_the_oracle(dev, monkeypatch):
     for z in (z0, z1):
         assert np.linalg.norm(z - ref) <= 1e-5 * np.linalg.norm(ref)
     assert np.linalg.norm(z1 - z0) <= 2e-6 * np.linalg.norm(z0)
+
+
+def test_ttlinear_long_k_bf16_inference_uses_the_recovered_weight(dev):
+    """DeiT-small fc2 (1536 -> 384, ranks (1,18,256,30,1)) in bf16 inference: the dense product with the recovered weight
+    (the dispatch rule of TTLinearM._dense_pays) against the fp32 chain of the same cores; qkv (K = 384) keeps the chain."""
+    from tadmm import tt_layers
+    hp = HP()
+    hp.tt_shapes = {"fc2": (24, 16, 32, 48), "qkv": (36, 32, 16, 24)}
+    hp.ranks = {"fc2": (1, 18, 256, 30, 1), "qkv": (1, 25, 256, 18, 1)}
+    torch.manual_seed(7)
+    fc2 = tt_layers.TTLinearM(1536, 384, bias=True, hp_dict=hp, name="fc2").to(dev).eval()
+    qkv = tt_layers.TTLinearM(384, 1152, bias=True, hp_dict=hp, name="qkv").to(dev).eval()
+    x2 = torch.randn(197, 1536, device=dev)
+    assert fc2._dense_pays(x2.bfloat16(), 256) and not fc2._dense_pays(x2, 256)
+    assert not qkv._dense_pays(torch.zeros(1, 384, device=dev, dtype=torch.bfloat16), 256)
+    with torch.no_grad():
+        ref = fc2(x2)                                    # fp32: the chain kernel (three bf16 planes)
+        got = fc2(x2.bfloat16()).float()
+    assert fc2.__dict__["_chain_cache"]["dense"] is not None
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 3e-2 * scale          # bf16 activations and weights: ~3 significant digits
+    # weight changes are seen (cache keyed like the chain's)
+    with torch.no_grad():
+        fc2.tt_cores[0].mul_(2.0)
+        got2 = fc2(x2.bfloat16()).float()
+        ref2 = fc2(x2)
+    assert float((got2 - ref2).abs().max()) <= 3e-2 * float(ref2.abs().max())
+    assert float((got2 - got).abs().max()) > 0.1 * scale
