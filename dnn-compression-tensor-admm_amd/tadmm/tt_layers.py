@@ -379,10 +379,13 @@ class TTLinearM(_TTLinearBase):
                     # kernel reuses a weight tile across 256 tokens -- 0.027 vs 0.020 ms.  Inference therefore multiplies by
                     # the recovered weight (cached with the other inference state), exactly what TTLinearR does every call
                     # (TTLinear.py:151-160).
-                    if cache.get("dense") is None:
+                    bkey = None if self.bias is None else HF.param_key(self.bias)
+                    if cache.get("dense") is None or cache.get("dense_bkey") != bkey:
                         with torch.no_grad():
                             cache["dense"] = HF.mm(w_out, w_in).to(x.dtype).contiguous()
-                    return F.linear(x, cache["dense"], None if self.bias is None else self.bias.to(x.dtype))
+                            cache["dense_bias"] = None if self.bias is None else self.bias.detach().to(x.dtype)
+                            cache["dense_bkey"] = bkey
+                    return F.linear(x, cache["dense"], cache["dense_bias"])
                 return HF.linear_chain(x, w_in, w_out, self.bias, cache["planes"])
         if x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or self.tt_cores[0].requires_grad)):
             return self._forward_bf16(x)
