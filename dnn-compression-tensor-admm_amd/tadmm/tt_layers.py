@@ -358,6 +358,13 @@ class TTLinearM(_TTLinearBase):
         """TTLinear.py:75-93.  One launch (`tadmm_ttlinear_fwd`) when the middle rank fits the fused kernel: the
         input cores are contracted into Win, the output cores into Wout, and y = Wout (Win x) + bias with the
         rank-r_q vector of a token held in LDS.  Otherwise the per-core GEMM chain below."""
+        if not torch.is_grad_enabled():
+            # inference fast path: the launch closure of the previous call, valid while no parameter changed (version
+            # counters and storage addresses).  The full dispatch below costs more host time than a 20 us kernel takes.
+            c = self.__dict__.get("_chain_cache")
+            if c is not None and c.get("fast_dtype") is x.dtype and c.get("fast_dev") == x.device \
+                    and c.get("fast_key") == HF.param_key(*self.tt_cores, self.bias):
+                return c["fast"](x)
         if self._fused_ok(x):
             grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.tt_cores)
             if grad and x.dtype == torch.float32:
@@ -385,8 +392,15 @@ class TTLinearM(_TTLinearBase):
                             cache["dense"] = HF.mm(w_out, w_in).to(x.dtype).contiguous()
                             cache["dense_bias"] = None if self.bias is None else self.bias.detach().to(x.dtype)
                             cache["dense_bkey"] = bkey
-                    return F.linear(x, cache["dense"], cache["dense_bias"])
-                return HF.linear_chain(x, w_in, w_out, self.bias, cache["planes"])
+                    dense, dbias = cache["dense"], cache["dense_bias"]
+                    fast = lambda t: F.linear(t, dense, dbias)
+                else:
+                    bias, planes = self.bias, cache["planes"]
+                    fast = lambda t: HF.linear_chain(t, w_in, w_out, bias, planes)
+                if not torch.is_grad_enabled():
+                    cache.update(fast=fast, fast_dtype=x.dtype, fast_dev=x.device,
+                                 fast_key=HF.param_key(*self.tt_cores, self.bias))
+                return fast(x)
         if x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or self.tt_cores[0].requires_grad)):
             return self._forward_bf16(x)
         return self._forward_chain(x)
