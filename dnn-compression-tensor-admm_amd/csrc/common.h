@@ -78,6 +78,7 @@ struct EigDesc {
   double* warm;       // jacobi_small only, nullable: [Npad][Npad] eigenvectors of this problem's PREVIOUS solve (row j =
                       // vector of column j); the solve then starts from X = G * V_prev instead of X = G
   int32_t* warm_ok;   // [1] the image is valid (written by a converged solve whose spectrum allowed normalising every column)
+  double* scratch;    // optional: 4 * N * N doubles of global scratch -- the problem may take the direct route of tridiag_mid.hip
   int32_t period;     // ticks per sweep of the GROUP's schedule (tick3 groups; 0: this problem's own players - 1): with one
                       // period for every problem of a group all sweeps start at the same tick, so the self pass is launched
                       // once per global sweep; a problem with fewer players idles in the ticks beyond its own
@@ -125,6 +126,11 @@ void launch_jacobi_small(const EigDesc* descs_dev, int nprob, int npad_max, doub
 // tridiag.hip: direct solver (tridiagonalisation + bisection + inverse iteration) for problems of at most 64 columns;
 // verified results only, everything else is left to jacobi_small_kernel
 bool eig_small_direct_on();
+// tridiag_mid.hip: the same route for the 128- / 192-column Rayleigh-Ritz problems (EigDesc::scratch set), one launch per size
+bool eig_mid_direct_on();
+bool eig_mid_direct_size(int n);
+size_t eig_mid_scratch_bytes(int n);
+void launch_eig_mid_direct(const EigDesc* descs_dev, int nprob, int ns, const int32_t* skip, int* verdict_pinned, hipStream_t s);
 void launch_eig_small_direct(const EigDesc* descs_dev, int nprob, const int32_t* skip, int32_t* fast_done_dev,
                              int* verdict_pinned, hipStream_t s);
 void launch_eig_norms(const EigDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s,

@@ -364,6 +364,7 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     e.off = (double*)dev(off_off); e.done = (int32_t*)dev(done_off);
     e.lam = (double*)dev(lam_off); e.order = (int32_t*)dev(ord_off); e.sigma = sp.sigma;
     e.r = sp.r; e.mode = 2; e.evec_out = (double*)dev(vh_off); e.sblk = (double*)dev(sblk_off);
+    if (eig_mid_direct_on() && eig_mid_direct_size(rp)) e.scratch = (double*)dev(ar.take(eig_mid_scratch_bytes(rp)));    // direct route (tridiag_mid.hip)
     rr.norm_blocks = (rp + 3) / 4; rr.ext_blocks = (sp.r + 3) / 4;
     rr_out.push_back(rr);
     // block maps

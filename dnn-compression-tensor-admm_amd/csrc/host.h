@@ -238,6 +238,7 @@ struct EigGroup {
   bool aligned = false;             // every EigDesc carries period = gsteps: all sweeps start at the same tick
   bool warm = false;                // some EigDesc of the group carries a warm-start image (jacobi_small: second LDS image)
   const int* row_len = nullptr;     // per problem: ld of its X image (timing only: executed flops of a tick)
+  const int* mid_sizes = nullptr;   // per problem: 128 / 192 when it may take the direct route (EigDesc::scratch set), else 0
   std::function<void(hipStream_t)> after_init;   // tick path only: queued right after jacobi_init (which takes the scale
                                                  // of a problem from X = G), e.g. the warm start X <- V G of big problems
   // debug only
@@ -288,6 +289,32 @@ static inline int run_eig_group(tadmm_handle h, const EigGroup& g, PollCtx& poll
   bool all_done = false;
   int tick = 0, gs = 0, pending = -1, needed = 0;
   std::vector<char> known_done(g.neig, 0);   // what the host has learnt so far (lags the device by a sweep)
+  // Rayleigh-Ritz problems of 128 / 192 columns (EigDesc::scratch set by the filter layout): direct route first
+  // (tridiag_mid.hip), ONE launch per size instead of ~80; what it solves and verifies has its `done` word set and the
+  // tournament below skips it -- if that is every problem of the group the tournament is not queued at all.  The host has
+  // to know, so this costs one stream round trip per group.
+  if (g.mode >= 2 && g.mid_sizes && eig_mid_direct_on()) {
+    bool any192 = false, any128 = false;
+    for (int q = 0; q < g.neig; ++q) { any192 = any192 || g.mid_sizes[q] == 192; any128 = any128 || g.mid_sizes[q] == 128; }
+    if (any192 || any128) {
+      for (int q = 0; q <= g.neig; ++q) poll.host[q] = 0;
+      if (any192) launch_eig_mid_direct(g.ed, g.neig, 192, g.skip, poll.host, s);
+      if (any128) launch_eig_mid_direct(g.ed, g.neig, 128, g.skip, poll.host, s);
+      HIP_OK(h, hipEventRecord(poll.ev[0], s));
+      if (hipEventSynchronize(poll.ev[0]) != hipSuccess) CTX_FAIL(h, TADMM_ERR_HIP, "poll event failed");
+      bool every = true;
+      for (int q = 0; q < g.neig; ++q) {
+        known_done[q] = poll.host[1 + q] != 0;
+        every = every && (known_done[q] || g.players[q] < 2);
+      }
+      if (getenv("TADMM_MID_DEBUG")) {
+        int ok = 0, cand = 0;
+        for (int q = 0; q < g.neig; ++q) { ok += known_done[q] ? 1 : 0; cand += g.mid_sizes[q] ? 1 : 0; }
+        fprintf(stderr, "[tadmm] direct RR route: %d of %d candidates solved (%d problems in the group)\n", ok, cand, g.neig);
+      }
+      if (every) { *sweeps_out = 0; return TADMM_OK; }
+    }
+  }
   std::vector<double> h_off;
   std::vector<int> h_done;
   auto consume = [&]() -> int {

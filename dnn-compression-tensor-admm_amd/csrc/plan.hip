@@ -148,6 +148,7 @@ struct StepPlan {
   size_t prev_off_dev = 0;            // [neig] doubles of the convergence kernel
   std::vector<int> nb;            // per problem
   std::vector<int> row_len;       // per problem: ld of the X image (instrumented runs)
+  std::vector<int> mid;           // per problem: 128 / 192 when it may take the direct route of tridiag_mid.hip, else 0
   std::vector<int> layer_of;      // problem -> layer
   // filtered eigen-solver (filter_host.h): the problems of this level it serves keep their slot in the eig group,
   // where their r' x r' Rayleigh-Ritz problem replaces the full N x N one; the full variants form the fallback group
@@ -510,7 +511,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
         ed[p] = e;
       }
     }
-    struct EigMaps { std::vector<BlockRef> tick, self, norm, ext; std::vector<int> nb, row_len; int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0; size_t tick_lds = 0; };
+    struct EigMaps { std::vector<BlockRef> tick, self, norm, ext; std::vector<int> nb, row_len, mid; int gsteps = 0, mode = 0, ld_max = 0, npad_max = 0; size_t tick_lds = 0; };
     auto build_maps = [&](const std::vector<EigDesc>& descs) {
       EigMaps m;
       for (const EigDesc& e : descs) { m.ld_max = std::max(m.ld_max, e.ld); m.npad_max = std::max(m.npad_max, e.Npad); }
@@ -523,6 +524,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
         const int units = super ? e.nb / 2 : e.nb;       // players of the tournament
         m.nb.push_back(units);
         m.row_len.push_back(e.ld);
+        m.mid.push_back((e.scratch && eig_mid_direct_size(e.N) && e.N == e.Npad) ? e.N : 0);
         m.gsteps = std::max(m.gsteps, units - 1);
         for (int b = 0; b < units / 2; ++b) m.tick.push_back(BlockRef{pq, b});
         if (m.mode >= 2) for (int b = 0; b < units; ++b) m.self.push_back(BlockRef{pq, b});
@@ -544,7 +546,7 @@ static int layout_plan(tadmm_plan_s* P, const float* const* W, float* const* U, 
       EigMaps m = build_maps(ed);
       if (m.mode >= 2 && align_sweeps) for (EigDesc& e : ed) e.period = m.gsteps;
       sp.mode = m.mode; sp.super = m.mode >= 1; sp.tick_lds = m.tick_lds; sp.gsteps = m.gsteps;
-      sp.ld_max = m.ld_max; sp.npad_max = m.npad_max; sp.nb = m.nb; sp.row_len = m.row_len;
+      sp.ld_max = m.ld_max; sp.npad_max = m.npad_max; sp.nb = m.nb; sp.row_len = m.row_len; sp.mid = m.mid;
       place(sp.eig_tick, ed.data(), ed.size() * sizeof(EigDesc), sp.neig, m.tick);
       sp.eig_desc_off = sp.eig_tick.desc_off;
       place_map(sp.eig_self, sp.eig_tick, m.self);
@@ -1092,6 +1094,7 @@ static int single_run(tadmm_plan p, int update_u, int use_u, double* resid_sq_de
     const int32_t* skip = filtered ? (const int32_t*)D(sp.skip_off) : nullptr;
     EigGroup eg;
     eg.ed = ed; eg.neig = sp.neig; eg.players = sp.nb.data(); eg.gsteps = sp.gsteps; eg.mode = sp.mode; eg.aligned = sp.mode >= 2 && align_sweeps_on(); eg.row_len = sp.row_len.data();
+    eg.mid_sizes = sp.mid.empty() ? nullptr : sp.mid.data();
     eg.ld_max = sp.ld_max; eg.tick_lds = sp.tick_lds;
     eg.tick_map = (const BlockRef*)D(sp.eig_tick.map_off); eg.tick_blocks = sp.eig_tick.nblocks;
     eg.self_map = (const BlockRef*)D(sp.eig_self.map_off); eg.self_blocks = sp.eig_self.nblocks;

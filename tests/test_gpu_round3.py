@@ -244,6 +244,43 @@ def test_complement_route_is_opt_in_and_matches_the_oracle(dev, monkeypatch):
     assert np.linalg.norm(z1 - z0) <= 2e-6 * np.linalg.norm(z0)
 
 
+@pytest.mark.parametrize("shape,r", [((256, 1024), 80), ((384, 1024), 120)])
+def test_direct_rayleigh_ritz_route_is_opt_in_and_matches_the_oracle(dev, monkeypatch, shape, r):
+    """The one-launch direct solve of the 128- / 192-column Rayleigh-Ritz problems (csrc/tridiag_mid.hip, TADMM_MID_DIRECT=1;
+    off by default: slower than the tournament as measured in round 3): same Z as the oracle and as the default path, and
+    no fallback of the filtered solve either way."""
+    from oracle import tt_oracle as O
+    from tadmm import ops
+    from tadmm._cabi import KIND_SVD
+    rng = np.random.default_rng(31)
+    # a decaying spectrum: separated Ritz values, the case the route is meant for
+    a = rng.standard_normal(shape)
+    u, s, vt = np.linalg.svd(a, full_matrices=False)
+    w = ((u * (s * np.exp(-np.arange(len(s)) / 40.0))) @ vt).astype(np.float32)
+    ref = O.prune_linear_rank_svd(w, r)
+
+    def run(flag):
+        if flag is None:
+            monkeypatch.delenv("TADMM_MID_DIRECT", raising=False)
+        else:
+            monkeypatch.setenv("TADMM_MID_DIRECT", flag)
+        t = torch.from_numpy(w).to(dev)
+        L = dict(kind=KIND_SVD, W=t, U=torch.zeros_like(t), Z=torch.empty_like(t), ranks=r)
+        plan = ops.ProjectionPlan([L])
+        plan.run(update_u=False, use_u=False)
+        st = plan.filter_stats()
+        plan.close()
+        return L["Z"].cpu().numpy(), st
+
+    z0, st0 = run(None)
+    z1, st1 = run("1")
+    assert st0["eligible"] == 1 and st1["eligible"] == 1, (st0, st1)
+    assert st0["fallbacks"] == 0 and st1["fallbacks"] == 0, (st0, st1)
+    for z in (z0, z1):
+        assert np.linalg.norm(z - ref) <= 1e-5 * np.linalg.norm(ref)
+    assert np.linalg.norm(z1 - z0) <= 2e-6 * np.linalg.norm(z0)
+
+
 def test_ttlinear_long_k_bf16_inference_uses_the_recovered_weight(dev):
     """DeiT-small fc2 (1536 -> 384, ranks (1,18,256,30,1)) in bf16 inference: the dense product with the recovered weight
     (the dispatch rule of TTLinearM._dense_pays) against the fp32 chain of the same cores; qkv (K = 384) keeps the chain."""
