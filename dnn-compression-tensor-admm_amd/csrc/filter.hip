@@ -2,7 +2,7 @@
 // eigen-decomposition.  Replaces, for unfoldings whose kept rank is a fraction of N, the full block-Jacobi solve
 // behind numpy.linalg.svd (reference ttd.py:17) by
 //
-//   Chebyshev-filtered subspace iteration on a block of r' ~ 1.55 r vectors   (dgemm.hip: products with G)
+//   Chebyshev-filtered subspace iteration on a block of r' ~ 1.45 r vectors   (dgemm.hip: products with G)
 //   + Cholesky QR between filter stages                                        (chol.hip)
 //   + ONE Rayleigh-Ritz solve of the r' x r' projection  H = Q^T G Q           (jacobi.hip, the same kernels)
 //   + a posteriori verification of the Ritz pairs                              (residuals over spectral gaps)

@@ -92,7 +92,7 @@ def filter_block_size(N: int, r: int) -> int:
     """Mirror of csrc/filter_host.h: iteration block of the filtered eigen-solver (0: full solve)."""
     if N < 192 or r < 16:
         return 0
-    rp = -(-int(1.55 * r + 0.999) // 32) * 32
+    rp = -(-int(1.45 * r + 0.999) // 32) * 32
     if rp > 256:                      # capped block: still filtered while it keeps >= 1.15 of oversampling
         rp = 256
         if rp < 1.15 * r:

@@ -138,8 +138,10 @@ def test_two_rank_layer_sharding_matches_single_process():
 
 
 def test_latency_partition_isolates_the_long_chains():
-    """ResNet-50 table: the three layer4.x.conv2 chains set the iteration time; the latency-aware partition must give
-    each its own rank as soon as there are four, and never do worse than the FLOP-balanced split under the model."""
+    """ResNet-50 table: the three layer4.x.conv2 chains set the iteration time; the latency-aware partition must put
+    them on three different ranks as soon as there are four -- beside layers whose levels they share, which cost the
+    rank throughput but no latency: its modelled time stays within 5 % of the chain alone -- and never do worse than the
+    FLOP-balanced split under the model."""
     sys.path.insert(0, os.path.join(ROOT, "dnn-compression-tensor-admm_amd"))
     from tadmm import sched, workloads
     from tadmm._cabi import KIND_TT_CONV
@@ -159,5 +161,7 @@ def test_latency_partition_isolates_the_long_chains():
         assert t_lat <= t_lpt * (1 + 1e-9)
         if ws >= 4:
             for p in parts:
-                if heavy & set(p):
-                    assert len(p) == 1, (ws, [names[i] for i in p])
+                mine = heavy & set(p)
+                assert len(mine) <= 1, (ws, [names[i] for i in p])
+                for i in mine:
+                    assert sched.rank_time_us([prof[k] for k in p]) <= 1.05 * sched.rank_time_us([prof[i]]), (ws, [names[k] for k in p])

@@ -375,8 +375,8 @@ def test_filter_block_is_capped_not_refused():
     """csrc/filter_host.h and its mirror in sched.py: a preferred block wider than 256 columns is capped while it keeps at
     least 1.15 of oversampling (ResNet-18 layer4: r = 210 / 220), refused below that (r = 236) and by the 0.56 N rule."""
     from tadmm import sched
-    assert sched.filter_block_size(512, 105) == 192          # ResNet-50 layer4: unchanged
-    assert sched.filter_block_size(512, 130) == 224
+    assert sched.filter_block_size(512, 105) == 160          # ResNet-50 layer4: align32(1.45 r)
+    assert sched.filter_block_size(512, 130) == 192
     assert sched.filter_block_size(480, 210) == 256 and sched.filter_block_size(512, 220) == 256
     assert sched.filter_block_size(480, 236) == 0             # 256 / 236 = 1.08
     assert sched.filter_block_size(384, 256) == 0 and sched.filter_block_size(288, 256) == 0     # DeiT-small: nothing
