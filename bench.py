@@ -611,8 +611,11 @@ def main():
         from tadmm import fwdbench
         rows = fwdbench.run(dev)
         head = next((r for r in rows if "qkv" in r["layer"] and r["dtype"] == "bf16" and "roofline" in r), None)
-        out["forward"] = {"note": "module call (inference, weights packed once) vs the dense torch layer of the same "
-                                  "shape and dtype; roofline = chain kernel alone, executed bf16 MFMA flops",
+        out["forward"] = {"note": "module call (inference, weights packed once) vs the dense torch op of the same shape and "
+                                  "dtype.  speedup_vs_dense compares the two under hipGraph replay (20 calls per graph: device "
+                                  "time, the host out of the loop); ms / dense_ms / eager_speedup_vs_dense are eager calls, "
+                                  "which at these sizes are host-bound on both sides (~20 us of dispatch around 10-40 us "
+                                  "kernels) and measure Python overhead; roofline = chain kernel alone, executed bf16 MFMA flops",
                           "layers": rows, "roofline": None if head is None else head["roofline"]}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.config)

@@ -349,10 +349,15 @@ class TTLinearM(_TTLinearBase):
         return self.out_features % align == 0 or not HF._needs_grad(x, self.bias, *self.tt_cores)
 
     def _dense_pays(self, x, r_q: int) -> bool:
-        """bf16 inference only: the chain's flop count is at least 0.8 of the dense layer's and the reduction is long."""
-        if x.dtype != torch.bfloat16 or self.in_features < 1024:
+        """bf16 inference only.  The contracted chain costs r_q (in + out) multiply-adds per token, the dense layer in * out:
+        the recovered weight is used when the chain saves nothing (ratio >= 1: DeiT-small `proj`, 384 -> 384 through rank
+        256 -- 12.5 us against 10.5 for the dense product under graph replay) or saves little over a long reduction
+        (ratio >= 0.8 and in_features >= 1024: `fc2`).  `qkv` / `fc1` (ratio 0.89 / 0.83, K = 384) keep the chain kernel:
+        1.4 - 1.65x the dense product."""
+        if x.dtype != torch.bfloat16:
             return False
-        return r_q * (self.in_features + self.out_features) >= 0.8 * self.in_features * self.out_features
+        chain, dense = r_q * (self.in_features + self.out_features), self.in_features * self.out_features
+        return chain >= dense or (self.in_features >= 1024 and chain >= 0.8 * dense)
 
     def forward(self, x):
         """TTLinear.py:75-93.  One launch (`tadmm_ttlinear_fwd`) when the middle rank fits the fused kernel: the
@@ -360,10 +365,11 @@ class TTLinearM(_TTLinearBase):
         rank-r_q vector of a token held in LDS.  Otherwise the per-core GEMM chain below."""
         if not torch.is_grad_enabled():
             # inference fast path: the launch closure of the previous call, valid while no parameter changed (version
-            # counters and storage addresses).  The full dispatch below costs more host time than a 20 us kernel takes.
+            # counters and storage addresses).  The full dispatch below costs more host time than a 20 us kernel takes;
+            # the parameters are read from the modules' own dictionaries (indexing the ParameterList costs ~1 us an entry).
             c = self.__dict__.get("_chain_cache")
             if c is not None and c.get("fast_dtype") is x.dtype and c.get("fast_dev") == x.device \
-                    and c.get("fast_key") == HF.param_key(*self.tt_cores, self.bias):
+                    and c.get("fast_key") == HF.param_key(*self.tt_cores._parameters.values(), self._parameters.get("bias")):
                 return c["fast"](x)
         if self._fused_ok(x):
             grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.tt_cores)
@@ -399,7 +405,7 @@ class TTLinearM(_TTLinearBase):
                     fast = lambda t: HF.linear_chain(t, w_in, w_out, bias, planes)
                 if not torch.is_grad_enabled():
                     cache.update(fast=fast, fast_dtype=x.dtype, fast_dev=x.device,
-                                 fast_key=HF.param_key(*self.tt_cores, self.bias))
+                                 fast_key=HF.param_key(*self.tt_cores._parameters.values(), self._parameters.get("bias")))
                 return fast(x)
         if x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or self.tt_cores[0].requires_grad)):
             return self._forward_bf16(x)
