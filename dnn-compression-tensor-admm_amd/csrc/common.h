@@ -214,7 +214,8 @@ struct DgemmDesc {
 void launch_dgemm(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, bool b_transposed, hipStream_t s);
 // NT product with LDS-staged 64 x tile_n tiles, tile_n = 64 | 32 (block map: local = tile index over
 // ceil(M/64) x ceil(N/tile_n); K % 32 == 0; row partials of modes 2/3 per tile_n-column tile)
-void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n = 64);
+void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n = 64,
+                       int tile_m = 64);   // tile_m = 32: 32 x 32 tiles (tile_n is then 32 as well)
 // C <- coef[0]*C + coef[1]*P over M x ldc elements; block map: local = chunk of 1024 elements
 void launch_daxpby(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s);
 // dgemm3.hip: the same NT products with B = G at fp32 accuracy on the bf16 matrix cores (three-plane split).

@@ -224,18 +224,25 @@ constexpr int kDT = 64, kDK = 32, kDLd = kDK + 2;
 // KW = 2: eight waves, the second four take the upper half of every K chunk (partial sums folded through LDS at the
 // end).  A workgroup then keeps two waves on every SIMD of its CU and finishes in half the time: the grouped launches
 // of the filter put about one workgroup on a CU, whose duration IS the launch's.
-template <int TN, int KW>
-__global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc* __restrict__ descs,
-                                                               const BlockRef* __restrict__ map) {
+// TM = 32 (with KW = 4: the same eight waves, four K quarters of a 32 x 32 tile): half the work per workgroup again.  A
+// workgroup's duration is its share of the fp64 matrix rate of ONE CU (a 64 x 32 x 480 tile is 2 MFLOP = 11 us at the
+// ~176 GFLOP/s a CU issues), and a product launch of the critical chain has 45 - 135 such workgroups on 256 CUs: the
+// smaller tile buys latency with operand traffic (each workgroup still streams its 32 rows of G).
+template <int TN, int KW, int TM = kDT>
+__global__ __launch_bounds__(128 * (TM / 32) * KW) void dgemm_nt_tile_kernel(const DgemmDesc* __restrict__ descs,
+                                                                            const BlockRef* __restrict__ map) {
+  constexpr int NT = 128 * (TM / 32) * KW;      // threads: (TM / 32) x 2 waves per K slice
   constexpr int WN = TN / 2;            // columns per wave
   constexpr int NB = WN / 16;           // B fragments per wave and k-step
-  constexpr int AP = 4 / KW;            // 16-byte pieces of A per thread and chunk (64 rows x 16 pieces / NT threads)
-  constexpr int BP = TN / 16 / KW;      // same for B (TN rows)
-  constexpr int RS = 16 * KW;           // row stride of a thread's pieces
-  constexpr int CPT = TN / 4;           // output columns per thread in the epilogue
-  constexpr int kBuf = (kDT + TN) * kDLd;          // doubles per LDS stage (A rows then B rows)
-  __shared__ __attribute__((aligned(16))) double smem[2 * kBuf > kDT * (TN + 1) ? 2 * kBuf : kDT * (TN + 1)];
-  __shared__ double rowred[kDT][4];
+  constexpr int AP = TM * 16 / NT;      // 16-byte pieces of A per thread and chunk (TM rows x 16 pieces / NT threads)
+  constexpr int BP = TN * 16 / NT;      // same for B (TN rows)
+  constexpr int RS = NT / 16;           // row stride of a thread's pieces
+  constexpr int TPR = 256 / TM;         // threads per output row in the epilogue (256 threads)
+  constexpr int CPT = TN / TPR;         // output columns per thread in the epilogue
+  constexpr int kBuf = (TM + TN) * kDLd;           // doubles per LDS stage (A rows then B rows)
+  static_assert(AP >= 1 && BP >= 1 && CPT >= 2, "tile / thread layout");
+  __shared__ __attribute__((aligned(16))) double smem[2 * kBuf > TM * (TN + 1) ? 2 * kBuf : TM * (TN + 1)];
+  __shared__ double rowred[TM][TPR];
   const BlockRef br = map[blockIdx.x];
   const DgemmArgs d = dg_args(descs + br.prob);
   if (d.gate && *d.gate < d.gate_min) return;
@@ -245,10 +252,10 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   G<double>* __restrict__ C = gp(const_cast<double*>(dg_sel(d, d.selC, d.C, base)));
   const int tiles_n = (d.N + TN - 1) / TN;
   const int tm = br.local / tiles_n, tn = br.local - tm * tiles_n;
-  const int m0 = tm * kDT, n0 = tn * TN;
+  const int m0 = tm * TM, n0 = tn * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int kh = (TM == 64) ? wave >> 2 : wave >> 1, wm = (TM == 64) ? (wave >> 1) & 1 : 0, wn = wave & 1;
   const int K = d.K;
   const int64_t lda = d.lda, ldb = d.ldb;
   const bool live = (m0 + 32 * wm < d.M) && (n0 + WN * wn < d.N);      // this wave's block exists
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   };
   auto sstore = [&](const Regs& R, int stage) {
     double (*As)[kDLd] = reinterpret_cast<double (*)[kDLd]>(smem + stage * kBuf);
-    double (*Bs)[kDLd] = As + kDT;
+    double (*Bs)[kDLd] = As + TM;
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<double2_t*>(&As[srow + RS * i][2 * sc2]) = R.a[i];
 #pragma unroll
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   auto compute = [&](int stage) {
     if (!live) return;
     const double (*As)[kDLd] = reinterpret_cast<const double (*)[kDLd]>(smem + stage * kBuf);
-    const double (*Bs)[kDLd] = As + kDT;
+    const double (*Bs)[kDLd] = As + TM;
     const int kof = kh * (kDK / KW);                                      // this wave's part of the chunk
     const double* a0p = &As[32 * wm + r][q + kof];
     const double* a1p = &As[32 * wm + 16 + r][q + kof];
@@ -344,37 +351,30 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   }
   // accumulators -> LDS tile [64][TN+1] (aliases the staging buffers; the loop's last barrier has passed)
   double (*Ct)[TN + 1] = reinterpret_cast<double (*)[TN + 1]>(smem);
-  if (KW == 2) {                        // upper k-half first, then the lower half adds its own sums
-    if (kh == 1) {
+  // the K slices fold their sums through LDS: the last slice writes, the others add in turn, slice 0 last
+#pragma unroll
+  for (int h = KW - 1; h >= 0; --h) {
+    if (kh == h) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NB; ++j) Ct[32 * wm + 16 * i + q + 4 * e][WN * wn + 16 * j + r] = acc[i][j][e];
+          for (int j = 0; j < NB; ++j) {
+            double* c = &Ct[32 * wm + 16 * i + q + 4 * e][WN * wn + 16 * j + r];
+            *c = (h == KW - 1 ? 0.0 : *c) + acc[i][j][e];
+          }
     }
     __syncthreads();
   }
-  if (kh == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          double* c = &Ct[32 * wm + 16 * i + q + 4 * e][WN * wn + 16 * j + r];
-          *c = (KW == 2 ? *c : 0.0) + acc[i][j][e];
-        }
-  }
-  __syncthreads();
-  if (KW == 2 && tid >= 256) return;    // the epilogue is laid out for 256 threads
+  if (NT > 256 && tid >= 256) return;   // the epilogue is laid out for 256 threads
   const int mode = d.mode;
   double s0 = 1.0, s1 = 0.0, s2 = 0.0;
   if (mode == 1) { s0 = d.coef[0]; s1 = d.coef[1]; s2 = d.coef[2]; }
   const G<const double>* __restrict__ P = gp((mode >= 1) ? dg_sel(d, d.selP, d.P, base) : nullptr);
   const G<const double>* __restrict__ Q = gp((mode == 1 && s2 != 0.0) ? dg_sel(d, d.selQ, d.Q, base) : nullptr);
   const int64_t ldc = d.ldc;
-  const int row = tid >> 2, c0 = (tid & 3) * CPT;
+  const int row = tid / TPR, c0 = (tid % TPR) * CPT;
   const bool rok = m0 + row < d.M;
   double part = 0.0;
   if (rok && n0 + c0 < d.N) {                                            // N % 16 == 0: a thread's columns are in or out together
@@ -407,16 +407,18 @@ __global__ __launch_bounds__(256 * KW) void dgemm_nt_tile_kernel(const DgemmDesc
   }
   DSTAMP(40);
   if (mode >= 2) {
-    rowred[row][tid & 3] = part;
+    rowred[row][tid % TPR] = part;
     __syncthreads();
-    if (tid < kDT && m0 + tid < d.M) {
+    if (tid < TM && m0 + tid < d.M) {
       const double* pr = rowred[tid];
-      d.rowpart[(int64_t)tn * d.M + m0 + tid] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      double sum = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      if (TPR == 8) sum += (pr[4] + pr[5]) + (pr[6] + pr[7]);
+      d.rowpart[(int64_t)tn * d.M + m0 + tid] = sum;
     }
   }
 }
 
-void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n) {
+void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int nblocks, hipStream_t s, int tile_n, int tile_m) {
   if (nblocks <= 0) return;
 #ifdef TADMM_DGEMM_STAMPS
   if (getenv("TADMM_DGEMM_STAMPS_DUMP")) {
@@ -431,6 +433,10 @@ void launch_dgemm_nt64(const DgemmDesc* descs_dev, const BlockRef* map_dev, int 
   // eight waves (two K halves) by default: two waves per SIMD issue fp64 MFMAs at 45 instead of 33-35 TF/s chip-wide
   // (scripts/micro/mfma_f64_peak.hip); worth 1.6 % of the ResNet-50 iteration, neutral elsewhere.  TADMM_DGEMM_KW=1: four.
   static const int kw = getenv("TADMM_DGEMM_KW") ? atoi(getenv("TADMM_DGEMM_KW")) : 2;
+  if (tile_m == 32) {                   // 32 x 32 tiles, four K quarters (filter products; filter_tile_m())
+    hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 4, 32>), dim3(nblocks), dim3(512), 0, s, descs_dev, map_dev);
+    return;
+  }
   if (tile_n == 32) {
     if (kw == 2) hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 2>), dim3(nblocks), dim3(512), 0, s, descs_dev, map_dev);
     else hipLaunchKernelGGL((dgemm_nt_tile_kernel<32, 1>), dim3(nblocks), dim3(256), 0, s, descs_dev, map_dev);

@@ -47,6 +47,21 @@ static inline int filter_tile_n() {
   const char* e = getenv("TADMM_FILTER_TN");
   return (e && atoi(e) == 64) ? 64 : 32;
 }
+// Rows of a product tile for a group of problems whose 64-row tiling has `tiles64` workgroups per product launch and whose
+// widest block has rp_max columns: 32 (32 x 32 tiles, twice the workgroups, half the duration each) while the launch is
+// latency-bound -- even the doubled count leaves the chip (256 CUs) about one workgroup per CU -- and the blocks are
+// narrow (r' <= 192: at most 6 row tiles re-stream a 32-row panel of G); 64 otherwise.  A workgroup's duration is its
+// share of ONE CU's fp64 matrix rate (a 64 x 32 x 480 tile is 2 MFLOP = 11 us at ~176 GFLOP/s), so halving the tile halves
+// the launch as long as there are CUs to spare.  Measured (separate processes, one box): ResNet-50 (levels of 160 - 288
+// tiles, r' = 160 / 192) 6.54 -> 6.27 ms per iteration with 32; ResNet-18 (256-column blocks, 120 - 380 tiles a level, the
+// other lane saturated by full tournaments) 8.81 -> 9.16 with 32.  TADMM_FILTER_TM = 32 | 64 forces one.
+static inline int filter_tile_m(int tiles64, int rp_max) {
+  if (const char* e = getenv("TADMM_FILTER_TM")) return atoi(e) == 32 ? 32 : 64;
+  if (filter_tile_n() != 32) return 64;
+  int limit = 288;
+  if (const char* e = getenv("TADMM_FILTER_TM_TILES")) limit = atoi(e);
+  return (tiles64 <= limit && rp_max <= 192) ? 32 : 64;
+}
 
 struct FilterSpec {
   int N = 0, Npad = 0, ldg = 0, r = 0, rp = 0;
@@ -119,6 +134,7 @@ struct FilterGroup {
   size_t cchol_off = 0, csolve_map_off = 0; int csolve_blocks = 0;
   int npad_max = 0, rp_max = 0;              // LDS of the guard kernel
   int max_degree = 8;
+  int tile_m = 64;                           // rows of a product tile (filter_tile_m)
   size_t prob_off = 0;                       // FiltProb[nf]
   Phase init, stage0, p1, axpby, tfinal, hform, uform, verify, emit;
   std::vector<Phase> steps;                  // recurrence steps k = 2 .. max_degree
@@ -173,6 +189,14 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     if (all_wide) fg.max_degree = 12;
   }
   if (const char* e = getenv("TADMM_FILTER_DEGREE")) fg.max_degree = std::max(2, std::min(16, atoi(e)));
+  {
+    int tiles64 = 0, rp_max = 0;
+    for (const FilterSpec& f : specs) {
+      tiles64 += ((f.rp + 63) / 64) * ((f.Npad + filter_tile_n() - 1) / filter_tile_n());
+      rp_max = std::max(rp_max, f.rp);
+    }
+    fg.tile_m = filter_tile_m(tiles64, rp_max);
+  }
   const int D = fg.max_degree;
   std::vector<FiltProb> probs(nf);
   std::vector<DgemmDesc> d_stage0(nf), d_p1(nf), d_axpby(nf), d_tfinal(nf), d_hform(nf), d_uform(nf), d_verify(nf),
@@ -199,7 +223,8 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     const FilterSpec& sp = specs[i];
     const int rp = sp.rp, Npad = sp.Npad, r32 = (int)align_up(sp.r, 32), ldy = Npad, ldh = (int)align_up(rp, 128);
     const int TNW = filter_tile_n();
-    const int tn = (Npad + TNW - 1) / TNW, tr = (rp + 63) / 64;      // 64 x TNW tiles of the NT products with G
+    const int TMW = fg.tile_m;
+    const int tn = (Npad + TNW - 1) / TNW, tr = (rp + TMW - 1) / TMW;      // TMW x TNW tiles of the NT products with G
     size_t ring_off[3];
     for (auto& o : ring_off) o = ar.take((size_t)rp * ldy * 8);
     const size_t st_off = ar.take(sizeof(FiltState));
@@ -359,7 +384,7 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
       c.gate = w_alive; c.gate_min = 1;
       c_comp.push_back(c);
       for (int b = 0; b < (cr + 3) / 4; ++b) { m_cform.push_back(BlockRef{ci, b}); m_cemit.push_back(BlockRef{ci, b}); }
-      for (int b = 0; b < ((cr + 63) / 64) * ((cr + TNW - 1) / TNW); ++b) m_cgram.push_back(BlockRef{ci, b});
+      for (int b = 0; b < ((cr + TMW - 1) / TMW) * ((cr + TNW - 1) / TNW); ++b) m_cgram.push_back(BlockRef{ci, b});
       for (int b = 0; b < (int)align_up(Npad, 64) / 64; ++b) m_csolve.push_back(BlockRef{ci, b});
     }
 
@@ -383,7 +408,7 @@ static inline void filter_layout(FilterGroup& fg, const std::vector<FilterSpec>&
     for (int b = 0; b < (gnt * gks + 3) / 4; ++b) m_gp.push_back(BlockRef{i, b});
     for (int b = 0; b < tr * ((rp + TNW - 1) / TNW); ++b) { m_gram.push_back(BlockRef{i, b}); m_hform.push_back(BlockRef{i, b}); }
     for (int b = 0; b < (r32 / 32) * (Npad / 32); ++b) m_uform.push_back(BlockRef{i, b});     // NN kernel: 32x32 tiles
-    for (int b = 0; b < ((r32 + 63) / 64) * tn; ++b) m_verify.push_back(BlockRef{i, b});
+    for (int b = 0; b < ((r32 + TMW - 1) / TMW) * tn; ++b) m_verify.push_back(BlockRef{i, b});
     for (int b = 0; b < (sp.r + 3) / 4; ++b) m_emit.push_back(BlockRef{i, b});
     for (int b = 0; b < (int)align_up(Npad, 64) / 64; ++b) m_solve.push_back(BlockRef{i, b});
     (void)vh_off;
@@ -486,7 +511,7 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   auto gemm = [&](const Phase& ph) {
     const bool t = tm && tm->on;
     if (t) (void)hipEventRecord(tm->a, s);
-    launch_dgemm_nt64((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, s, filter_tile_n());
+    launch_dgemm_nt64((const DgemmDesc*)D(ph.desc_off), (const BlockRef*)D(ph.map_off), ph.nblocks, s, filter_tile_n(), fg.tile_m);
     if (t) {
       float ms = 0.f;
       (void)hipEventRecord(tm->b, s);
@@ -581,7 +606,7 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
   {
     const bool t = tm && tm->on;
     if (t) (void)hipEventRecord(tm->a, s);
-    launch_dgemm_nt64((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, s, filter_tile_n());
+    launch_dgemm_nt64((const DgemmDesc*)D(fg.verify.desc_off), (const BlockRef*)D(fg.verify.map_off), fg.verify.nblocks, s, filter_tile_n(), fg.tile_m);
     if (t) {
       float ms = 0.f;
       (void)hipEventRecord(tm->b, s);
@@ -594,7 +619,7 @@ static inline int filter_run_post(tadmm_handle h, FilterGroup& fg, char* ws, Pol
     const CompDesc* cd = (const CompDesc*)D(fg.comp_off);        // problem bad BEFORE the verdict is taken
     launch_comp_form(cd, (const BlockRef*)D(fg.cform.map_off), fg.cform.nblocks, s);
     for (int pass = 0; pass < 2; ++pass) {
-      launch_dgemm_nt64((const DgemmDesc*)D(fg.cgram.desc_off), (const BlockRef*)D(fg.cgram.map_off), fg.cgram.nblocks, s, filter_tile_n());
+      launch_dgemm_nt64((const DgemmDesc*)D(fg.cgram.desc_off), (const BlockRef*)D(fg.cgram.map_off), fg.cgram.nblocks, s, filter_tile_n(), fg.tile_m);
       launch_chol_factor((const CholDesc*)D(fg.cchol_off), fg.ncomp, s);
       launch_chol_solve((const CholDesc*)D(fg.cchol_off), (const BlockRef*)D(fg.csolve_map_off), fg.csolve_blocks, s);
     }
