@@ -586,7 +586,8 @@ static inline int filter_run_pre(tadmm_handle h, FilterGroup& fg, char* ws, Poll
   gemm(fg.tfinal);
   gemm(fg.hform);
   if (filter_moments_on()) launch_filt_moments(probs, fg.nf, s);     // H is about to be overwritten by its own eigen-solve
-  if (debug) fprintf(stderr, "[tadmm] filter: %d problems, %d stages of <= %d steps\n", fg.nf, stages, fg.max_degree);
+  if (debug) fprintf(stderr, "[tadmm] filter: %d problems, %d stages of <= %d steps, product tiles %d x %d (%d blocks a launch)\n", fg.nf, stages,
+                     fg.max_degree, fg.tile_m, filter_tile_n(), fg.p1.nblocks);
   return TADMM_OK;
 }
 
