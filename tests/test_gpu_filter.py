@@ -108,6 +108,27 @@ def test_filtered_projection_matches_full_solve_and_oracle(dev, monkeypatch):
         assert np.linalg.norm(z - ref) <= 1e-5 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("tm", ["32", "64"])
+def test_product_tile_heights_agree(dev, monkeypatch, tm):
+    """The filter products run on 32 x 32 tiles (four K quarters per workgroup) for latency-bound levels of narrow blocks and
+    on 64 x 32 tiles otherwise (csrc/filter_host.h: filter_tile_m); TADMM_FILTER_TM forces one.  Both against the full solve
+    and the oracle on the same layers, no fallback either way."""
+    rng = np.random.default_rng(3)
+    specs, layers, ws = _layers(dev, rng)
+    monkeypatch.setenv("TADMM_FILTER_TM", tm)
+    zf, st_f, sv_f = _run(layers, True, monkeypatch)
+    monkeypatch.delenv("TADMM_FILTER_TM")
+    zn, _, sv_n = _run(layers, False, monkeypatch)
+    assert st_f["eligible"] == 3 and st_f["solves"] == 3 and st_f["fallbacks"] == 0, st_f
+    for a, b in zip(zf, zn):
+        assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
+    for a, b in zip(sv_f, sv_n):
+        np.testing.assert_allclose(a, b, rtol=1e-9)
+    for (shape, tts, ranks), w, z in zip(specs, ws, zf):
+        ref = O.prune_conv_rank_tt(w, tts, list(ranks))
+        assert np.linalg.norm(z - ref) <= 1e-5 * np.linalg.norm(ref)
+
+
 def test_filtered_projection_is_deterministic(dev, monkeypatch):
     rng = np.random.default_rng(4)
     _, layers, _ = _layers(dev, rng)
