@@ -291,6 +291,7 @@ struct FiltParams {
   int32_t max_degree;         // recurrence steps per stage (D)
   double log_target;          // ln(2/eps): wanted total log-amplification
   double cond_max;            // largest tolerated growth of the block's condition number per stage
+  double cond_first;          // the same for the first stage, whose bounds come from the Rayleigh quotients of one power step
   double sin_tol;             // acceptance threshold of the verification
   double log_precise;         // log-amplification the fp64 stages must contribute once fp32-accuracy stages were used
 };

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void filt_plan_kernel(const FiltProb* __restri
         const double ln2 = 0.6931471805599453;
         // the first stage only has the Rayleigh quotients of one power step to go by, which under-estimate lambda_1
         // (and with it the growth of the block's condition number): keep it short
-        const double cmax = st->stage == 0 ? fmin(prm.cond_max, 1e4) : prm.cond_max;
+        const double cmax = st->stage == 0 ? fmin(prm.cond_max, prm.cond_first) : prm.cond_max;
         int mc = (int)floor(log(2.0 * cmax) / a1);
         mc = max(1, mc);
         int mn = (int)ceil((need + ln2) / ar);

@@ -488,6 +488,7 @@ static inline FiltParams filter_params(const FilterGroup& fg) {
   prm.max_degree = fg.max_degree;
   prm.log_target = log(2.0 / 1e-11);
   prm.cond_max = 1e6;
+  prm.cond_first = 1e4;
   prm.sin_tol = 1e-5;
   prm.log_precise = log(100.0);
   // complement levels (trailing end of the spectrum: dense, tiny gaps behind the boundary) are held to a tighter target:
@@ -496,6 +497,7 @@ static inline FiltParams filter_params(const FilterGroup& fg) {
   if (const char* e = getenv("TADMM_FILTER_LOG_PRECISE")) prm.log_precise = atof(e);
   if (const char* e = getenv("TADMM_FILTER_EPS")) prm.log_target = log(2.0 / atof(e));
   if (const char* e = getenv("TADMM_FILTER_COND")) prm.cond_max = atof(e);
+  if (const char* e = getenv("TADMM_FILTER_COND_FIRST")) prm.cond_first = atof(e);
   if (const char* e = getenv("TADMM_FILTER_SINTOL")) prm.sin_tol = atof(e);
   return prm;
 }
